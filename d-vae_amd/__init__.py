@@ -1,0 +1,10 @@
+"""MI355X-native implementation of the D-VAE hot path (train step + purification pass).
+
+Host code is Python on PyTorch-ROCm; all arithmetic on the path runs in hand-written gfx950 HIP
+kernels behind the C ABI of ``include/dvae_hip.h`` (``lib/libdvae_hip.so``, built by ``make``).
+"""
+from . import _lib
+from ._lib import BF16, F32
+from .engine import DVAEConfig, DVAEEngine
+
+__all__ = ["_lib", "F32", "BF16", "DVAEConfig", "DVAEEngine"]

@@ -1,0 +1,372 @@
+// libdvae_hip.so: extern "C" entry points (declared in include/dvae_hip.h) over the gfx950 kernels.
+// Host code here only validates shapes, derives launch geometry and launches on the caller's stream.
+#include "common.hpp"
+#include "elementwise.hpp"
+#include "igemm.hpp"
+#include "norm.hpp"
+
+namespace dvae {
+thread_local char g_err[512] = "";
+}
+using namespace dvae;
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int grid_for(long n, int block = 256, int cap = 2048) {
+    long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+static inline int act_c(int C, int dtype) {
+    int c = act_channels(C);
+    if (dtype == DVAE_BF16 && c < 8) c = 8;
+    return c;
+}
+
+#define DISPATCH_T(dtype, ...)                                   \
+    if ((dtype) == DVAE_F32) { using T = float; __VA_ARGS__ }    \
+    else if ((dtype) == DVAE_BF16) { using T = bf16; __VA_ARGS__ } \
+    else DVAE_FAIL(DVAE_EDTYPE, "unknown dtype %d", (dtype));
+
+extern "C" {
+
+const char* dvae_version(void) { return "dvae_hip 0.1 (gfx950)"; }
+const char* dvae_last_error(void) { return g_err; }
+int dvae_act_channels(int C) { return act_channels(C); }
+
+// ---------------------------------------------------------------------------------------------
+int dvae_u8_to_act(const uint8_t* u8, const int32_t* index, int64_t first, void* act, int B, int HW, int dtype, void* st) {
+    if (B <= 0 || HW <= 0) DVAE_FAIL(DVAE_EINVAL, "u8_to_act: empty");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((u8_to_act_kernel<T>), dim3(grid_for((long)B * HW)), dim3(256), 0, S(st), u8,
+                                         index, (long)first, (T*)act, B, HW, act_c(3, dtype));)
+    DVAE_CHECK_LAUNCH("u8_to_act");
+    return DVAE_OK;
+}
+
+int dvae_nchw_to_act(const float* nchw, void* act, int B, int C, int H, int W, int dtype, void* st) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) DVAE_FAIL(DVAE_EINVAL, "nchw_to_act: empty");
+    const int CS = act_c(C, dtype);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_act_kernel<T>), dim3(grid_for((long)B * H * W * CS)), dim3(256), 0,
+                                         S(st), nchw, (T*)act, B, C, H * W, CS);)
+    DVAE_CHECK_LAUNCH("nchw_to_act");
+    return DVAE_OK;
+}
+
+int dvae_act_to_nchw(const void* act, float* nchw, int B, int C, int H, int W, int act_channels_, int coff,
+                     int act_is_f32, int dtype, void* st) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || coff < 0 || coff + C > act_channels_)
+        DVAE_FAIL(DVAE_EINVAL, "act_to_nchw: bad shape");
+    const int dt = act_is_f32 ? DVAE_F32 : dtype;
+    DISPATCH_T(dt, hipLaunchKernelGGL((act_to_nchw_kernel<T>), dim3(grid_for((long)B * C * H * W)), dim3(256), 0, S(st),
+                                      (const T*)act, nchw, B, C, H * W, act_channels_, coff);)
+    DVAE_CHECK_LAUNCH("act_to_nchw");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t dvae_conv_packed_elems(const dvae_conv_desc* d, int op) {
+    GemmPlan P;
+    // element count is the same for both dtypes only if BK matches; report the larger (bf16, BK = 64)
+    if (!d || build_plan(*d, op, DVAE_BF16, P)) return 0;
+    return (size_t)P.Npad * P.Ktot;
+}
+
+int dvae_conv_pack(const float* w, void* out, const dvae_conv_desc* d, int op, int dtype, void* st) {
+    GemmPlan P;
+    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
+    int rc = build_plan(*d, op, dtype, P);
+    if (rc) return rc;
+    PackArgs a;
+    a.w = w; a.out = out; a.N = P.N; a.Npad = P.Npad; a.Cg = P.Cg; a.cg_log2 = P.cg_log2; a.Ktot = P.Ktot;
+    a.sN = P.sN; a.sC = P.sC; a.nphase = P.nphase;
+    for (int i = 0; i < 4; ++i) a.pk[i] = P.pk[i];
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid_for((long)P.Npad * P.Ktot)), dim3(256), 0,
+                                         S(st), a);)
+    DVAE_CHECK_LAUNCH("conv_pack");
+    return DVAE_OK;
+}
+
+int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* y, const dvae_conv_desc* d, int dtype,
+                  void* st) {
+    GemmPlan P;
+    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
+    int rc = build_plan(*d, DVAE_OP_FWD, dtype, P);
+    if (rc) return rc;
+    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0};
+    if (ep) e = *ep;
+    if (dtype == DVAE_F32)
+        return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
+    DVAE_FAIL(DVAE_EDTYPE, "conv_fwd: dtype %d not built", dtype);
+}
+
+int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, const dvae_conv_desc* d, int dtype,
+                    void* st) {
+    GemmPlan P;
+    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
+    int rc = build_plan(*d, DVAE_OP_DGRAD, dtype, P);
+    if (rc) return rc;
+    if (dtype == DVAE_F32)
+        return launch_igemm<float>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 1, S(st));
+    DVAE_FAIL(DVAE_EDTYPE, "conv_dgrad: dtype %d not built", dtype);
+}
+
+size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d) {
+    WgradPlan W;
+    if (!d || build_wgrad_plan(*d, DVAE_BF16, W)) return 0;
+    size_t a = wgrad_workspace_floats(W);
+    if (build_wgrad_plan(*d, DVAE_F32, W)) return 0;
+    size_t b = wgrad_workspace_floats(W);
+    return (a > b ? a : b) * sizeof(float);
+}
+
+int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                    const dvae_conv_desc* d, int dtype, void* st) {
+    WgradPlan W;
+    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
+    int rc = build_wgrad_plan(*d, dtype, W);
+    if (rc) return rc;
+    if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
+    if (dtype != DVAE_F32) DVAE_FAIL(DVAE_EDTYPE, "conv_wgrad: dtype %d not built", dtype);
+    WgradArgs a;
+    a.xg = d->transposed ? dy : x;
+    a.d = d->transposed ? x : dy;
+    a.ws = (float*)ws;
+    a.B = W.B; a.Hx = W.Hx; a.Wx = W.Wx; a.cx_log2 = W.cx_log2; a.Hg = W.Hg; a.Wg = W.Wg; a.SY = W.SY; a.SX = W.SX;
+    a.CdS = W.CdS; a.ntaps = W.ntaps;
+    memcpy(a.dy, W.dy, 16); memcpy(a.dx, W.dx, 16);
+    a.M = W.M; a.chunk_rows = W.chunk_rows; a.Kpad = W.Kpad; a.CdPad = W.CdPad;
+    hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
+    DVAE_CHECK_LAUNCH("wgrad");
+    WreduceArgs r;
+    r.ws = (const float*)ws; r.dw = dw; r.S = W.S; r.Kpad = W.Kpad; r.CdPad = W.CdPad; r.Cx = W.Cx;
+    r.cx_log2 = W.cx_log2; r.Cd = W.Cd; r.ntaps = W.ntaps; r.sX = W.sX; r.sD = W.sD;
+    memcpy(r.woff, W.woff, sizeof(r.woff));
+    const long tot = (long)W.Kpad * W.CdPad;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, S(st), r);
+    DVAE_CHECK_LAUNCH("wgrad_reduce");
+    if (db) {
+        float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
+        const void* src = dy;
+        const int CS = W.bias_from_gathered ? W.CxS : W.CdS;
+        const int rows = W.bias_from_gathered ? W.B * W.Hx * W.Wx : W.M;
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(COLSUM_BLOCKS), dim3(256), 0, S(st), (const float*)src,
+                           part, rows, CS);
+        DVAE_CHECK_LAUNCH("colsum_partial");
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->Cout + 63) / 64), dim3(64), 0, S(st), part, db, COLSUM_BLOCKS,
+                           CS, d->Cout);
+        DVAE_CHECK_LAUNCH("colsum_reduce");
+    }
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t dvae_norm_workspace_bytes(int groups, int rows_per_group, int C) {
+    if (groups <= 0 || rows_per_group <= 0 || C <= 0) return 0;
+    return norm_ws_floats(norm_geom(groups, rows_per_group, C)) * sizeof(float);
+}
+
+static int norm_check(int groups, int rows_per_group, int C, int dtype) {
+    const int vec = dtype == DVAE_BF16 ? 8 : 4;
+    if (groups <= 0 || rows_per_group <= 0 || C < vec || (C & (C - 1)) || C / vec > 256)
+        DVAE_FAIL(DVAE_EINVAL, "norm: C must be a power of two in [%d, %d]", vec, 256 * vec);
+    if ((long)groups * rows_per_group * C > 0x7fffffffL * 4) DVAE_FAIL(DVAE_EINVAL, "norm: tensor too large");
+    return DVAE_OK;
+}
+
+int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* ws,
+                        size_t ws_bytes, int groups, int rows_per_group, int C, int relu, float momentum, float eps,
+                        int dtype, void* st) {
+    int rc = norm_check(groups, rows_per_group, C, dtype);
+    if (rc) return rc;
+    const NormGeom g = norm_geom(groups, rows_per_group, C);
+    if (ws_bytes < norm_ws_floats(g) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "norm workspace too small");
+    float* partial = (float*)ws;
+    float* scale_shift = partial + (size_t)groups * g.nchunk * 3 * C + (size_t)groups * 3 * C;
+    const long nvec = (long)groups * rows_per_group * C / (dtype == DVAE_BF16 ? 8 : 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((norm_stats_kernel<T>), dim3(g.nchunk, groups), dim3(256), 0, S(st), (const T*)x,
+                                  partial, rows_per_group, C, g.rows_per_chunk, g.nchunk);
+               DVAE_CHECK_LAUNCH("norm_stats");
+               hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 31) / 32, groups), dim3(256), 0, S(st), partial,
+                                  g.nchunk, C, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                                  scale_shift, momentum, eps);
+               DVAE_CHECK_LAUNCH("norm_finalize");
+               hipLaunchKernelGGL((norm_apply_kernel<T>), dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, S(st),
+                                  (const T*)x, (const T*)res, (T*)y, scale_shift, rows_per_group, C, nvec, relu);)
+    DVAE_CHECK_LAUNCH("norm_apply");
+    return DVAE_OK;
+}
+
+int dvae_bn_fold_eval(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
+                      float* shift, int C, float eps, void* st) {
+    if (C <= 0) DVAE_FAIL(DVAE_EINVAL, "bn_fold: C <= 0");
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, S(st), gamma, beta, rm, rv, scale, shift, C, eps);
+    DVAE_CHECK_LAUNCH("bn_fold_eval");
+    return DVAE_OK;
+}
+
+int dvae_bn_fwd_eval(const void* x, const void* res, void* y, const float* gamma, const float* beta, const float* rm,
+                     const float* rv, float* scale_shift, int rows, int C, int relu, float eps, int dtype, void* st) {
+    int rc = norm_check(1, rows, C, dtype);
+    if (rc) return rc;
+    rc = dvae_bn_fold_eval(gamma, beta, rm, rv, scale_shift, scale_shift + C, C, eps, st);
+    if (rc) return rc;
+    const long nvec = (long)rows * C / (dtype == DVAE_BF16 ? 8 : 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((norm_apply_kernel<T>), dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, S(st),
+                                         (const T*)x, (const T*)res, (T*)y, scale_shift, rows, C, nvec, relu);)
+    DVAE_CHECK_LAUNCH("bn_apply_eval");
+    return DVAE_OK;
+}
+
+int dvae_norm_bwd(const void* dy, const void* y, const void* x, void* dx, void* dres, const float* gamma,
+                  const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* ws,
+                  size_t ws_bytes, int groups, int rows_per_group, int C, int relu, int dtype, void* st) {
+    int rc = norm_check(groups, rows_per_group, C, dtype);
+    if (rc) return rc;
+    if ((dgamma || dbeta) && groups != 1) DVAE_FAIL(DVAE_EINVAL, "affine gradients need a single group");
+    const NormGeom g = norm_geom(groups, rows_per_group, C);
+    if (ws_bytes < norm_ws_floats(g) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "norm workspace too small");
+    float* partial = (float*)ws;
+    float* coef = partial + (size_t)groups * g.nchunk * 3 * C;
+    const long nvec = (long)groups * rows_per_group * C / (dtype == DVAE_BF16 ? 8 : 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((norm_bwd_reduce_kernel<T>), dim3(g.nchunk, groups), dim3(256), 0, S(st),
+                                  (const T*)dy, (const T*)y, (const T*)x, save_mean, save_invstd, partial,
+                                  rows_per_group, C, g.rows_per_chunk, g.nchunk, relu);
+               DVAE_CHECK_LAUNCH("norm_bwd_reduce");
+               hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 31) / 32, groups), dim3(256), 0, S(st), partial,
+                                  g.nchunk, C, rows_per_group, gamma, save_invstd, coef, dgamma, dbeta);
+               DVAE_CHECK_LAUNCH("norm_bwd_finalize");
+               hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, S(st),
+                                  (const T*)dy, (const T*)y, (const T*)x, (T*)dx, (T*)dres, save_mean, save_invstd,
+                                  coef, rows_per_group, C, nvec, relu);)
+    DVAE_CHECK_LAUNCH("norm_bwd_apply");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int dvae_emb_add_fwd(const float* emb, const int64_t* y, const void* add, void* out, int B, int HW, int C, int spatial,
+                     int dtype, void* st) {
+    if (B <= 0 || HW <= 0 || C <= 0) DVAE_FAIL(DVAE_EINVAL, "emb_add: empty");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((emb_add_kernel<T>), dim3(grid_for((long)B * HW * C)), dim3(256), 0, S(st), emb,
+                                         y, (const T*)add, (T*)out, B, HW, C, spatial);)
+    DVAE_CHECK_LAUNCH("emb_add");
+    return DVAE_OK;
+}
+
+int dvae_emb_bwd(const void* dout, const int64_t* y, float* demb, int B, int HW, int C, int num_classes, int spatial,
+                 int dtype, void* st) {
+    if (B <= 0 || HW <= 0 || C <= 0 || num_classes <= 0) DVAE_FAIL(DVAE_EINVAL, "emb_bwd: empty");
+    const long total = (long)num_classes * (spatial ? (long)C * HW : C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((emb_bwd_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, S(st),
+                                         (const T*)dout, y, demb, B, HW, C, num_classes, spatial);)
+    DVAE_CHECK_LAUNCH("emb_bwd");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int dvae_philox_normal(float* out, const int32_t* index, int64_t first, int B, int per_image, uint64_t seed,
+                       uint32_t stream_id, void* st) {
+    if (B <= 0 || per_image <= 0 || per_image % 4) DVAE_FAIL(DVAE_EINVAL, "philox: per_image must be a positive multiple of 4");
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, S(st), out, index,
+                       (long)first, B, per_image, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id);
+    DVAE_CHECK_LAUNCH("philox_normal");
+    return DVAE_OK;
+}
+
+int dvae_reparam_kl_fwd(const float* mulv, const float* eps, void* z1, float* kl_partial, int rows, int L, int dtype,
+                        void* st) {
+    if (rows <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), mulv, eps,
+                                         (T*)z1, kl_partial, rows, L);)
+    DVAE_CHECK_LAUNCH("reparam_kl_fwd");
+    return DVAE_OK;
+}
+
+int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal, void* dmulv, int rows,
+                        int L, int dtype, void* st) {
+    if (rows <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_bwd_kernel<T>), dim3(grid_for((long)rows * L / 4)), dim3(256), 0,
+                                         S(st), (const T*)dz1, mulv, eps, scal, (T*)dmulv, rows, L);)
+    DVAE_CHECK_LAUNCH("reparam_kl_bwd");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int dvae_recon_loss_fwd(const void* rec_pre, const void* p, const void* x, float* rec, float* partial, int npix,
+                        int dtype, void* st) {
+    if (npix <= 0) DVAE_FAIL(DVAE_EINVAL, "recon_loss: empty");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((recon_loss_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st),
+                                         (const T*)rec_pre, (const T*)p, (const T*)x, rec, partial, npix, act_c(3, dtype));)
+    DVAE_CHECK_LAUNCH("recon_loss_fwd");
+    return DVAE_OK;
+}
+
+int dvae_loss_reduce(const float* recon_partial, const float* kl_partial, float* sums, void* st) {
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, S(st), recon_partial, kl_partial, sums);
+    DVAE_CHECK_LAUNCH("loss_reduce");
+    return DVAE_OK;
+}
+
+int dvae_loss_gate(const float* sums, float* scal, double n_elem, double rows, double local_n_elem, double local_rows,
+                   float kld_target, float kld_weight, int epoch_gt_10, void* st) {
+    if (n_elem <= 0 || rows <= 0 || local_n_elem <= 0 || local_rows <= 0) DVAE_FAIL(DVAE_EINVAL, "loss_gate: counts");
+    hipLaunchKernelGGL(loss_gate_kernel, dim3(1), dim3(64), 0, S(st), sums, scal, n_elem, rows, local_n_elem,
+                       local_rows, kld_target, kld_weight, epoch_gt_10);
+    DVAE_CHECK_LAUNCH("loss_gate");
+    return DVAE_OK;
+}
+
+int dvae_recon_loss_bwd(const float* rec, const void* p, const void* x, const float* scal, void* d_rec_pre, void* d_p,
+                        int npix, int dtype, void* st) {
+    if (npix <= 0) DVAE_FAIL(DVAE_EINVAL, "recon_loss: empty");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((recon_loss_bwd_kernel<T>), dim3(grid_for(npix)), dim3(256), 0, S(st), rec,
+                                         (const T*)p, (const T*)x, scal, (T*)d_rec_pre, (T*)d_p, npix, act_c(3, dtype));)
+    DVAE_CHECK_LAUNCH("recon_loss_bwd");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int dvae_purify_quant(const void* a, const void* b, int a_is_f32, void* v_out, uint8_t* u8, int64_t first, int B, int HW,
+                      int dtype, void* st) {
+    if (B <= 0 || HW <= 0) DVAE_FAIL(DVAE_EINVAL, "purify_quant: empty");
+    const int CS = act_c(3, dtype);
+    const int g = grid_for((long)B * HW);
+    if (dtype == DVAE_F32 || (a_is_f32 && dtype == DVAE_BF16)) {
+        if (dtype == DVAE_F32)
+            hipLaunchKernelGGL((purify_quant_kernel<float, float>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4,
+                               (const float*)b, CS, (float*)v_out, u8, (long)first, B, HW);
+        else
+            hipLaunchKernelGGL((purify_quant_kernel<float, bf16>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4,
+                               (const bf16*)b, CS, (bf16*)v_out, u8, (long)first, B, HW);
+    } else if (dtype == DVAE_BF16) {
+        hipLaunchKernelGGL((purify_quant_kernel<bf16, bf16>), dim3(g), dim3(256), 0, S(st), (const bf16*)a, CS,
+                           (const bf16*)b, CS, (bf16*)v_out, u8, (long)first, B, HW);
+    } else {
+        DVAE_FAIL(DVAE_EDTYPE, "unknown dtype %d", dtype);
+    }
+    DVAE_CHECK_LAUNCH("purify_quant");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int dvae_sqnorm_partial(const float* g, int64_t n, float* partial, void* st) {
+    if (n <= 0) DVAE_FAIL(DVAE_EINVAL, "sqnorm: empty");
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), g, (long)n, partial);
+    DVAE_CHECK_LAUNCH("sqnorm_partial");
+    return DVAE_OK;
+}
+
+int dvae_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, const float* partial,
+                   float* scal, void* st) {
+    if (n <= 0) DVAE_FAIL(DVAE_EINVAL, "clip_adam: empty");
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, S(st), p, g, m, v, (long)n, hyper,
+                       partial, scal);
+    DVAE_CHECK_LAUNCH("clip_adam");
+    hipLaunchKernelGGL(hyper_tick_kernel, dim3(1), dim3(64), 0, S(st), hyper);
+    DVAE_CHECK_LAUNCH("hyper_tick");
+    return DVAE_OK;
+}
+
+}  // extern "C"

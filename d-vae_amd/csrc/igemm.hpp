@@ -1,0 +1,561 @@
+// Implicit-GEMM convolution family for gfx950 (MFMA, LDS-staged gathered tiles).
+//
+// One "gather GEMM" covers Conv2d forward, Conv2d input-gradient, ConvTranspose2d forward and
+// ConvTranspose2d input-gradient:
+//
+//     out[dst(m), n] = sum_{t < ntaps} sum_{c < Cg}  in[src(m, t), c] * W[n, t, c]
+//
+// m enumerates (b, y, x) of an output sub-grid ("phase"); src(m,t) = (b, y*SY + dy[t], x*SX + dx[t])
+// (zero outside the tensor); dst(m) = (b, y*DSY + D0Y, x*DSX + D0X).  A stride-s transposed gather
+// (Conv2d dgrad, ConvTranspose2d forward) is split into s*s phases by output parity so that no MFMA
+// work is spent on taps that never hit.  Activations are NHWC, so the GEMM K index (t, c) is
+// contiguous in memory per tap and a 16-byte vector never straddles taps.
+//
+// The weight-gradient kernel contracts over pixels instead:
+//     dW[t, cx, cd] = sum_m  X[src(m, t), cx] * D[m, cd]
+// with per-chunk partial slabs in a caller-provided workspace that a second kernel sums in a fixed
+// order and scatters into the reference's weight layout (deterministic, no float atomics).
+#pragma once
+#include "common.hpp"
+
+namespace dvae {
+
+struct Phase {
+    int Hg, Wg;           // sub-grid of output positions handled by this phase
+    int SY, SX;           // source step per grid step
+    int DSY, DSX, D0Y, D0X;
+    int ntaps;
+    int koff;             // first K column of this phase in the packed weight rows
+    signed char dy[16], dx[16];
+};
+
+struct PackPhase {
+    int ntaps, koff, kcols;   // kcols = K columns of this phase, padded to a multiple of BK
+    int woff[16];             // ky*kw + kx of each tap in the reference weight
+};
+
+struct GemmPlan {
+    int B;
+    int Hin, Win, Cg, CgS, cg_log2;   // gathered tensor (logical / padded channels)
+    int Hout, Wout, N, NS, Npad;      // output tensor; N logical, NS act channel stride
+    int nphase;
+    Phase ph[4];
+    PackPhase pk[4];
+    int Ktot;
+    int sN, sC;                       // reference weight index = n*sN + c*sC + woff
+};
+
+static inline int act_channels(int C) {
+    int p = 4;
+    while (p < C) p <<= 1;
+    return p;
+}
+
+// Build the gather plan of op (DVAE_OP_FWD / DVAE_OP_DGRAD) for a conv descriptor.
+static int build_plan(const dvae_conv_desc& d, int op, int dtype, GemmPlan& P) {
+    if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 ||
+        d.stride <= 0 || d.pad < 0 || d.kh * d.kw > 16 || d.stride > 2)
+        DVAE_FAIL(DVAE_EINVAL, "conv desc out of range (kh*kw <= 16, stride <= 2)");
+    if (dtype != DVAE_F32 && dtype != DVAE_BF16) DVAE_FAIL(DVAE_EDTYPE, "unknown dtype %d", dtype);
+    const int BK = dtype == DVAE_F32 ? 32 : 64;
+    const int s = d.stride, p = d.pad;
+    int Ho, Wo;
+    if (!d.transposed) {
+        Ho = (d.H + 2 * p - d.kh) / s + 1;
+        Wo = (d.W + 2 * p - d.kw) / s + 1;
+    } else {
+        Ho = (d.H - 1) * s - 2 * p + d.kh;
+        Wo = (d.W - 1) * s - 2 * p + d.kw;
+    }
+    if (Ho <= 0 || Wo <= 0) DVAE_FAIL(DVAE_EINVAL, "empty conv output");
+    memset(&P, 0, sizeof(P));
+    P.B = d.B;
+    // direct gather: Conv2d fwd, ConvT dgrad.  transposed gather: Conv2d dgrad, ConvT fwd.
+    const bool direct = (!d.transposed && op == DVAE_OP_FWD) || (d.transposed && op == DVAE_OP_DGRAD);
+    const int kk = d.kh * d.kw;
+    if (!d.transposed && op == DVAE_OP_FWD) {        // x -> y
+        P.Hin = d.H; P.Win = d.W; P.Cg = d.Cin; P.Hout = Ho; P.Wout = Wo; P.N = d.Cout;
+        P.sN = d.Cin * kk; P.sC = kk;
+    } else if (!d.transposed) {                      // dy -> dx
+        P.Hin = Ho; P.Win = Wo; P.Cg = d.Cout; P.Hout = d.H; P.Wout = d.W; P.N = d.Cin;
+        P.sN = kk; P.sC = d.Cin * kk;
+    } else if (op == DVAE_OP_FWD) {                  // convT: x -> y   (weight [Cin][Cout][kh][kw])
+        P.Hin = d.H; P.Win = d.W; P.Cg = d.Cin; P.Hout = Ho; P.Wout = Wo; P.N = d.Cout;
+        P.sN = kk; P.sC = d.Cout * kk;
+    } else {                                         // convT: dy -> dx
+        P.Hin = Ho; P.Win = Wo; P.Cg = d.Cout; P.Hout = d.H; P.Wout = d.W; P.N = d.Cin;
+        P.sN = d.Cout * kk; P.sC = kk;
+    }
+    P.CgS = act_channels(P.Cg);
+    if (dtype == DVAE_BF16 && P.CgS < 8) P.CgS = 8;
+    P.cg_log2 = ilog2_exact(P.CgS);
+    P.NS = act_channels(P.N);
+    if (dtype == DVAE_BF16 && P.NS < 8) P.NS = 8;
+    P.Npad = round_up(P.NS, 32);
+    int koff = 0;
+    if (direct) {
+        P.nphase = 1;
+        Phase& ph = P.ph[0];
+        ph.Hg = P.Hout; ph.Wg = P.Wout; ph.SY = s; ph.SX = s; ph.DSY = 1; ph.DSX = 1; ph.D0Y = 0; ph.D0X = 0;
+        ph.ntaps = kk; ph.koff = 0;
+        for (int ky = 0; ky < d.kh; ++ky)
+            for (int kx = 0; kx < d.kw; ++kx) {
+                int t = ky * d.kw + kx;
+                ph.dy[t] = (signed char)(ky - p); ph.dx[t] = (signed char)(kx - p);
+                P.pk[0].woff[t] = t;
+            }
+        P.pk[0].ntaps = kk; P.pk[0].koff = 0; P.pk[0].kcols = round_up(kk * P.CgS, BK);
+        koff = P.pk[0].kcols;
+    } else {
+        P.nphase = s * s;
+        for (int py = 0; py < s; ++py)
+            for (int px = 0; px < s; ++px) {
+                int i = py * s + px;
+                Phase& ph = P.ph[i];
+                ph.Hg = (P.Hout - py + s - 1) / s; ph.Wg = (P.Wout - px + s - 1) / s;
+                ph.SY = 1; ph.SX = 1; ph.DSY = s; ph.DSX = s; ph.D0Y = py; ph.D0X = px;
+                int nt = 0;
+                for (int ky = 0; ky < d.kh; ++ky) {
+                    int vy = py + p - ky;
+                    if (((vy % s) + s) % s) continue;
+                    for (int kx = 0; kx < d.kw; ++kx) {
+                        int vx = px + p - kx;
+                        if (((vx % s) + s) % s) continue;
+                        ph.dy[nt] = (signed char)(vy / s); ph.dx[nt] = (signed char)(vx / s);
+                        P.pk[i].woff[nt] = ky * d.kw + kx;
+                        ++nt;
+                    }
+                }
+                ph.ntaps = nt; ph.koff = koff;
+                P.pk[i].ntaps = nt; P.pk[i].koff = koff; P.pk[i].kcols = round_up(nt * P.CgS, BK);
+                koff += P.pk[i].kcols;
+            }
+    }
+    P.Ktot = koff > 0 ? koff : BK;
+    return DVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: reference layout fp32 -> [Npad][Ktot] operand image (K contiguous), dtype T
+// ------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w;
+    void* out;
+    int N, Npad, Cg, cg_log2, Ktot, sN, sC, nphase;
+    PackPhase pk[4];
+};
+
+template <typename T>
+__global__ void pack_weight_kernel(const PackArgs a) {
+    const long total = (long)a.Npad * a.Ktot;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / a.Ktot), k = (int)(e % a.Ktot);
+        float v = 0.f;
+        if (n < a.N) {
+            for (int i = 0; i < a.nphase; ++i) {
+                const PackPhase& pk = a.pk[i];
+                if (k >= pk.koff && k < pk.koff + pk.kcols) {
+                    const int kk = k - pk.koff;
+                    const int tap = kk >> a.cg_log2, c = kk & ((1 << a.cg_log2) - 1);
+                    if (tap < pk.ntaps && c < a.Cg) v = a.w[(long)n * a.sN + (long)c * a.sC + pk.woff[tap]];
+                }
+            }
+        }
+        reinterpret_cast<T*>(a.out)[e] = (T)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather GEMM
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const void* in;
+    const void* wp;
+    void* out;
+    const float* scale;
+    const float* shift;
+    const void* res;
+    int B, Hin, Win, cg_log2;
+    int Hout, Wout, N, NS;
+    int Ktot;
+    int relu, accumulate, out_f32;
+    Phase ph[4];
+};
+
+constexpr int LDS_ROW = 144;   // bytes per staged tile row: 128 B of K data + 16 B pad (bank spread)
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    // 128-byte K slab = 32 floats.  v_mfma_f32_32x32x2_f32: lane (r = l&31, h = l>>5) supplies
+    // A[r][k=h] and B[k=h][r].  Each lane reads 4 consecutive floats at column 8q+4h, so MFMA e of
+    // group q contracts columns {8q+e, 8q+4+e}; A and B use the same map, the sum is unchanged.
+    __device__ static inline void run(const unsigned char* arow, const unsigned char* brow, int h, f32x16& acc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(arow + 32 * q + 16 * h);
+            f32x4 b = *reinterpret_cast<const f32x4*>(brow + 32 * q + 16 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+    }
+};
+
+template <typename T, int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
+    constexpr int BM = WGM * 32 * TM, BN = WGN * 32 * TN;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int BK = 8 * VEC;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDS_ROW];
+    __shared__ int rowdst[BM];
+    __shared__ int taptab[16];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * LDS_ROW;
+
+    const Phase& ph = a.ph[blockIdx.z];
+    const int M = a.B * ph.Hg * ph.Wg;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;
+    const int n0 = blockIdx.y * BN;
+    const int tid = threadIdx.x;
+    const int kvec = tid & 7, lrow = tid >> 3;
+
+    if (tid < 16) taptab[tid] = ((int)ph.dy[tid] << 16) | ((int)ph.dx[tid] & 0xffff);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int dst = -1;
+        if (m < M) {
+            const int x = m % ph.Wg, t = m / ph.Wg, y = t % ph.Hg, b = t / ph.Hg;
+            dst = (b * a.Hout + y * ph.DSY + ph.D0Y) * a.Wout + x * ph.DSX + ph.D0X;
+        }
+        rowdst[tid] = dst;
+    }
+    int pixbase[AP], sy[AP], sx[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < M) {
+            const int x = m % ph.Wg, t = m / ph.Wg, y = t % ph.Hg, b = t / ph.Hg;
+            pixbase[i] = b * a.Hin * a.Win; sy[i] = y * ph.SY; sx[i] = x * ph.SX;
+        } else {
+            pixbase[i] = 0; sy[i] = -(1 << 20); sx[i] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int cmask = (1 << a.cg_log2) - 1;
+    const int nk = ((ph.ntaps << a.cg_log2) + BK - 1) / BK;
+    const T* in = reinterpret_cast<const T*>(a.in);
+    const T* wp = reinterpret_cast<const T*>(a.wp) + ph.koff;
+
+    u32x4 areg[AP], breg[BP];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kvec * VEC;
+        const int tap = k >> a.cg_log2, c = k & cmask;
+        const bool tv = tap < ph.ntaps;
+        const int tt = taptab[tap & 15];
+        const int dy = tt >> 16, dx = (int)(short)(tt & 0xffff);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int iy = sy[i] + dy, ix = sx[i] + dx;
+            const bool ok = tv && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const long off = ((long)(pixbase[i] + iy * a.Win + ix) << a.cg_log2) + c;
+                v = *reinterpret_cast<const u32x4*>(in + off);
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int n = n0 + lrow + 32 * i;
+            breg[i] = *reinterpret_cast<const u32x4*>(wp + (long)n * a.Ktot + k);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<u32x4*>(As + (lrow + 32 * i) * LDS_ROW + kvec * 16) = areg[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            *reinterpret_cast<u32x4*>(Bs + (lrow + 32 * i) * LDS_ROW + kvec * 16) = breg[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WGN) * 32 * TM, wn0 = (wave % WGN) * 32 * TN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                Mfma<T>::run(As + (wm0 + 32 * i + r) * LDS_ROW, Bs + (wn0 + 32 * j + r) * LDS_ROW, h, acc[i][j]);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column n = ..+r and rows (e&3) + 8*(e>>2) + 4*h of each 32x32 tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 32 * j + r;
+        if (n >= a.NS) continue;
+        const bool live = n < a.N;
+        const float sc = (live && a.scale) ? a.scale[n] : 1.f;
+        const float sh = (live && a.shift) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ml = wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int dp = rowdst[ml];
+                if (dp < 0) continue;
+                const long o = (long)dp * a.NS + n;
+                float v = acc[i][j][e] * sc + sh;
+                if (a.res) v += (float)reinterpret_cast<const T*>(a.res)[o];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (!live) v = 0.f;
+                if (a.out_f32) {
+                    float* op = reinterpret_cast<float*>(a.out);
+                    if (a.accumulate) v += op[o];
+                    op[o] = v;
+                } else {
+                    T* op = reinterpret_cast<T*>(a.out);
+                    if (a.accumulate) v += (float)op[o];
+                    op[o] = (T)v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_igemm(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
+                        const float* shift, const void* res, int relu, int accumulate, int out_f32,
+                        hipStream_t st) {
+    GemmArgs a;
+    a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift; a.res = res;
+    a.B = P.B; a.Hin = P.Hin; a.Win = P.Win; a.cg_log2 = P.cg_log2;
+    a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+    int maxM = 0;
+    for (int i = 0; i < 4; ++i) a.ph[i] = P.ph[i];
+    for (int i = 0; i < P.nphase; ++i) {
+        long M = (long)P.B * P.ph[i].Hg * P.ph[i].Wg;
+        if (M > 0x7fffffffL / 2) DVAE_FAIL(DVAE_EINVAL, "too many output pixels for 32-bit indexing");
+        if ((int)M > maxM) maxM = (int)M;
+    }
+    if ((long)P.B * P.Hin * P.Win * P.CgS > 0x7fffffffL || (long)P.B * P.Hout * P.Wout * P.NS > 0x7fffffffL)
+        DVAE_FAIL(DVAE_EINVAL, "tensor exceeds 2^31 elements");
+    if (maxM == 0) return DVAE_OK;
+    constexpr int BM = 128;
+    dim3 block(256);
+    if (P.Npad % 128 == 0) {
+        dim3 grid((maxM + BM - 1) / BM, P.Npad / 128, P.nphase);
+        hipLaunchKernelGGL((igemm_kernel<T, 2, 2, 2, 2>), grid, block, 0, st, a);
+    } else if (P.Npad % 64 == 0) {
+        dim3 grid((maxM + BM - 1) / BM, P.Npad / 64, P.nphase);
+        hipLaunchKernelGGL((igemm_kernel<T, 2, 1, 2, 2>), grid, block, 0, st, a);
+    } else {
+        dim3 grid((maxM + BM - 1) / BM, P.Npad / 32, P.nphase);
+        hipLaunchKernelGGL((igemm_kernel<T, 1, 1, 4, 1>), grid, block, 0, st, a);
+    }
+    DVAE_CHECK_LAUNCH("igemm");
+    return DVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradPlan {
+    int B;
+    int Hx, Wx, Cx, CxS, cx_log2;   // gathered tensor
+    int Hg, Wg, Cd, CdS;            // dense tensor (rows m)
+    int SY, SX, ntaps;
+    signed char dy[16], dx[16];
+    int woff[16];
+    int sX, sD;                     // reference weight index = cd*sD + cx*sX + woff
+    int M, S, chunk_rows, Kpad, CdPad;
+    int bias_from_gathered;         // bias gradient = column sums of the gathered (1) or dense (0) tensor
+};
+
+static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
+    GemmPlan P;
+    int rc = build_plan(d, DVAE_OP_FWD, dtype, P);
+    if (rc) return rc;
+    memset(&W, 0, sizeof(W));
+    const int kk = d.kh * d.kw, p = d.pad, s = d.stride;
+    const int Ho = d.transposed ? P.Hout : P.Hout, Wo = P.Wout;   // module output dims
+    W.B = d.B;
+    if (!d.transposed) {   // X = x (gathered with stride s), D = dy
+        W.Hx = d.H; W.Wx = d.W; W.Cx = d.Cin; W.Hg = Ho; W.Wg = Wo; W.Cd = d.Cout;
+        W.sX = kk; W.sD = d.Cin * kk; W.bias_from_gathered = 0;
+    } else {               // X = dy (gathered with stride s), D = x; weight [Cin][Cout][kh][kw]
+        W.Hx = Ho; W.Wx = Wo; W.Cx = d.Cout; W.Hg = d.H; W.Wg = d.W; W.Cd = d.Cin;
+        W.sX = kk; W.sD = d.Cout * kk; W.bias_from_gathered = 1;
+    }
+    const int minc = dtype == DVAE_BF16 ? 8 : 4;
+    W.CxS = act_channels(W.Cx); if (W.CxS < minc) W.CxS = minc;
+    W.CdS = act_channels(W.Cd); if (W.CdS < minc) W.CdS = minc;
+    W.cx_log2 = ilog2_exact(W.CxS);
+    W.SY = s; W.SX = s; W.ntaps = kk;
+    for (int ky = 0; ky < d.kh; ++ky)
+        for (int kx = 0; kx < d.kw; ++kx) {
+            int t = ky * d.kw + kx;
+            W.dy[t] = (signed char)(ky - p); W.dx[t] = (signed char)(kx - p); W.woff[t] = t;
+        }
+    W.M = d.B * W.Hg * W.Wg;
+    W.Kpad = round_up(kk * W.CxS, 64);
+    W.CdPad = round_up(W.CdS, 64);
+    const int tiles = (W.Kpad / 64) * (W.CdPad / 64);
+    int S = 768 / tiles; if (S < 1) S = 1;
+    int chunk = round_up((W.M + S - 1) / S, 32); if (chunk < 32) chunk = 32;
+    W.chunk_rows = chunk;
+    W.S = (W.M + chunk - 1) / chunk;
+    return DVAE_OK;
+}
+
+constexpr int COLSUM_BLOCKS = 128;
+
+static size_t wgrad_workspace_floats(const WgradPlan& W) {
+    const int cs = W.bias_from_gathered ? W.CxS : W.CdS;
+    return (size_t)W.S * W.Kpad * W.CdPad + (size_t)COLSUM_BLOCKS * cs;
+}
+
+struct WgradArgs {
+    const void* xg;
+    const void* d;
+    float* ws;
+    int B, Hx, Wx, cx_log2, Hg, Wg, SY, SX, CdS, ntaps;
+    signed char dy[16], dx[16];
+    int M, chunk_rows, Kpad, CdPad;
+};
+
+// fp32: one 64(K) x 64(Cd) slab tile per workgroup, contraction over a chunk of pixels,
+// 32 pixels per LDS stage, v_mfma_f32_32x32x2_f32 with A[i = K column][k = pixel], B[k = pixel][j = cd].
+__global__ __launch_bounds__(256) void wgrad_kernel_f32(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[32 * 64];
+    __shared__ __attribute__((aligned(16))) float Ds[32 * 64];
+    const int tid = threadIdx.x, kv = tid & 15, rl = tid >> 4;
+    const int kbase = blockIdx.y * 64, cdbase = blockIdx.z * 64;
+    const int k = kbase + kv * 4;
+    const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
+    const bool tv = tap < a.ntaps;
+    const int dy = a.dy[tap & 15], dx = a.dx[tap & 15];
+    const int cd = cdbase + kv * 4;
+    const bool cv = cd < a.CdS;
+    const int mbeg = blockIdx.x * a.chunk_rows;
+    const int mend = min(a.M, mbeg + a.chunk_rows);
+    const float* xg = reinterpret_cast<const float*>(a.xg);
+    const float* dd = reinterpret_cast<const float*>(a.d);
+
+    f32x4 xr[2], dr[2];
+    auto load = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mb + rl + 16 * i;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+            if (m < mend) {
+                const int x = m % a.Wg, t = m / a.Wg, y = t % a.Hg, b = t / a.Hg;
+                const int iy = y * a.SY + dy, ix = x * a.SX + dx;
+                if (tv && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
+                    xv = *reinterpret_cast<const f32x4*>(xg + (((long)((b * a.Hx + iy) * a.Wx + ix)) << a.cx_log2) + c);
+                if (cv) dv = *reinterpret_cast<const f32x4*>(dd + (long)m * a.CdS + cd);
+            }
+            xr[i] = xv; dr[i] = dv;
+        }
+    };
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    if (mbeg < mend) load(mbeg);
+    for (int mb = mbeg; mb < mend; mb += 32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(rl + 16 * i) * 64 + kv * 4]) = xr[i];
+            *reinterpret_cast<f32x4*>(&Ds[(rl + 16 * i) * 64 + kv * 4]) = dr[i];
+        }
+        __syncthreads();
+        if (mb + 32 < mend) load(mb + 32);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float av = As[(2 * s + h) * 64 + wi * 32 + r];
+            const float bv = Ds[(2 * s + h) * 64 + wj * 32 + r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* ws = a.ws + ((long)blockIdx.x * a.Kpad + kbase + wi * 32) * a.CdPad + cdbase + wj * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ws[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * a.CdPad] = acc[e];
+}
+
+struct WreduceArgs {
+    const float* ws;
+    float* dw;
+    int S, Kpad, CdPad, Cx, cx_log2, Cd, ntaps, sX, sD;
+    int woff[16];
+};
+
+__global__ void wgrad_reduce_kernel(const WreduceArgs a) {
+    const long total = (long)a.Kpad * a.CdPad;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int k = (int)(e / a.CdPad), cd = (int)(e % a.CdPad);
+    const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
+    if (tap >= a.ntaps || c >= a.Cx || cd >= a.Cd) return;
+    float s = 0.f;
+    for (int i = 0; i < a.S; ++i) s += a.ws[(long)i * total + e];
+    a.dw[(long)cd * a.sD + (long)c * a.sX + a.woff[tap]] = s;
+}
+
+// column sums of an [rows][CS] activation tensor (bias gradients), two deterministic stages
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, float* partial, int rows, int CS) {
+    constexpr int VEC = Act<T>::VEC;
+    __shared__ float red[256 * VEC];
+    const int CV = CS / VEC, RL = 256 / CV;
+    const int cvi = threadIdx.x % CV, rl = threadIdx.x / CV;
+    float s[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+    if (rl < RL) {
+        for (long row = (long)blockIdx.x * RL + rl; row < rows; row += (long)gridDim.x * RL) {
+            float v[VEC];
+            Act<T>::load(x + row * CS + cvi * VEC, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x * VEC + i] = s[i];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < CS; ch += 256) {
+        const int cv2 = ch / VEC, i = ch % VEC;
+        float t = 0.f;
+        for (int q = 0; q < RL; ++q) t += red[(q * CV + cv2) * VEC + i];
+        partial[(long)blockIdx.x * CS + ch] = t;
+    }
+}
+
+__global__ void colsum_reduce_kernel(const float* partial, float* out, int nblk, int CS, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += partial[(long)i * CS + c];
+    out[c] = s;
+}
+
+}  // namespace dvae

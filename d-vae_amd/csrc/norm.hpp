@@ -1,0 +1,312 @@
+// BatchNorm2d(+residual)+ReLU and InstanceNorm2d+ReLU, forward and backward, on NHWC activations.
+//
+// Both are "normalise each channel over a group of rows": BatchNorm has one group of B*H*W rows,
+// InstanceNorm has B groups of H*W rows.  Statistics are fp32, computed in one pass over x as
+// (count, mean, M2) triples merged with Chan's parallel formula (no E[x^2]-E[x]^2 cancellation),
+// in a fixed order so results are bitwise reproducible.  All kernels are HBM-bound: 16-byte vector
+// accesses along the channel (innermost) dimension.
+#pragma once
+#include "common.hpp"
+
+namespace dvae {
+
+struct NormGeom {
+    int groups, rows_per_group, C;
+    int rows_per_chunk, nchunk;
+};
+
+static inline NormGeom norm_geom(int groups, int rows_per_group, int C) {
+    NormGeom g;
+    g.groups = groups; g.rows_per_group = rows_per_group; g.C = C;
+    // aim for >= ~1024 workgroups, chunks of >= 64 rows, at most 512 chunks per group
+    int want = (1024 + groups - 1) / groups;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    int rpc = (rows_per_group + want - 1) / want;
+    if (rpc < 64) rpc = 64;
+    g.rows_per_chunk = rpc;
+    g.nchunk = (rows_per_group + rpc - 1) / rpc;
+    return g;
+}
+
+// workspace (floats): partial [G][nchunk][3][C] | coef [G][3][C] | scale_shift [G][2][C]
+static inline size_t norm_ws_floats(const NormGeom& g) {
+    return (size_t)g.groups * g.nchunk * 3 * g.C + (size_t)g.groups * 5 * g.C;
+}
+
+__device__ inline void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    const float n = na + nb;
+    if (n > 0.f) {
+        const float d = mb - ma;
+        const float f = nb / n;
+        ma = ma + d * f;
+        qa = qa + qb + d * d * na * f;
+        na = n;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_stats_kernel(const T* x, float* partial, int rows_per_group, int C,
+                                                         int rows_per_chunk, int nchunk) {
+    constexpr int VEC = Act<T>::VEC;
+    __shared__ float sn[256], sm[256 * VEC], sq[256 * VEC];
+    const int CV = C / VEC, RL = 256 / CV;
+    const int cvi = threadIdx.x % CV, rl = threadIdx.x / CV;
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk;
+    const int nrows = min(rows_per_chunk, rows_per_group - r0);
+    const T* base = x + ((long)g * rows_per_group + r0) * C + cvi * VEC;
+    float s[VEC], ss[VEC], k0[VEC];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s[i] = 0.f; ss[i] = 0.f; k0[i] = 0.f; }
+    for (int r = rl; r < nrows; r += RL) {
+        float v[VEC];
+        Act<T>::load(base + (long)r * C, v);
+        if (cnt == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) k0[i] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const float d = v[i] - k0[i]; s[i] += d; ss[i] += d * d; }
+        ++cnt;
+    }
+    const float n = (float)cnt;
+    sn[threadIdx.x] = n;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float mean = k0[i], m2 = 0.f;
+        if (cnt > 0) { const float ms = s[i] / n; mean = k0[i] + ms; m2 = ss[i] - s[i] * ms; }
+        sm[threadIdx.x * VEC + i] = mean;
+        sq[threadIdx.x * VEC + i] = m2 < 0.f ? 0.f : m2;
+    }
+    __syncthreads();
+    for (int step = RL >> 1; step > 0; step >>= 1) {
+        if (rl < step) {
+            const int o = threadIdx.x + step * CV;
+            const float na = sn[threadIdx.x], nb = sn[o];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float a_n = na, a_m = sm[threadIdx.x * VEC + i], a_q = sq[threadIdx.x * VEC + i];
+                chan_merge(a_n, a_m, a_q, nb, sm[o * VEC + i], sq[o * VEC + i]);
+                sm[threadIdx.x * VEC + i] = a_m; sq[threadIdx.x * VEC + i] = a_q;
+            }
+            sn[threadIdx.x] = na + nb;
+        }
+        __syncthreads();
+    }
+    if (rl == 0) {
+        float* p = partial + ((long)(g * nchunk + chunk) * 3) * C + cvi * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            p[i] = sn[threadIdx.x];
+            p[C + i] = sm[threadIdx.x * VEC + i];
+            p[2 * C + i] = sq[threadIdx.x * VEC + i];
+        }
+    }
+}
+
+// One workgroup per (32-channel tile, group): 8 lanes per channel merge the chunk triples, then
+// mean / invstd / scale / shift are written and (BatchNorm) the running statistics are updated.
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial, int nchunk, int C,
+                                                            const float* gamma, const float* beta,
+                                                            float* running_mean, float* running_var,
+                                                            float* save_mean, float* save_invstd,
+                                                            float* scale_shift, float momentum, float eps) {
+    __shared__ float sn[256], sm[256], sq[256];
+    const int g = blockIdx.y;
+    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float n = 0.f, m = 0.f, q = 0.f;
+    if (c < C) {
+        for (int ch = lane8; ch < nchunk; ch += 8) {
+            const float* p = partial + ((long)(g * nchunk + ch) * 3) * C + c;
+            chan_merge(n, m, q, p[0], p[C], p[2 * C]);
+        }
+    }
+    sn[threadIdx.x] = n; sm[threadIdx.x] = m; sq[threadIdx.x] = q;
+    __syncthreads();
+    for (int step = 4; step > 0; step >>= 1) {
+        if (lane8 < step) {
+            const int o = threadIdx.x + step * 32;
+            float a_n = sn[threadIdx.x], a_m = sm[threadIdx.x], a_q = sq[threadIdx.x];
+            chan_merge(a_n, a_m, a_q, sn[o], sm[o], sq[o]);
+            sn[threadIdx.x] = a_n; sm[threadIdx.x] = a_m; sq[threadIdx.x] = a_q;
+        }
+        __syncthreads();
+    }
+    if (lane8 == 0 && c < C) {
+        const float cnt = sn[threadIdx.x], mean = sm[threadIdx.x];
+        const float var = sq[threadIdx.x] / cnt;
+        const float invstd = 1.0f / sqrtf(var + eps);
+        save_mean[(long)g * C + c] = mean;
+        save_invstd[(long)g * C + c] = invstd;
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        const float sc = ga * invstd;
+        scale_shift[((long)g * 2) * C + c] = sc;
+        scale_shift[((long)g * 2 + 1) * C + c] = be - mean * sc;
+        if (running_mean) {
+            const float unb = cnt > 1.f ? sq[threadIdx.x] / (cnt - 1.f) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
+    }
+}
+
+__global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                    float* scale, float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// y = relu?( x * scale[g][c] + shift[g][c] + residual )
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const T* x, const T* res, T* y, const float* scale_shift,
+                                                         int rows_per_group, int C, long nvec, int relu) {
+    constexpr int VEC = Act<T>::VEC;
+    const int CV = C / VEC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / CV;
+        const int cvi = (int)(i % CV);
+        const int g = (int)(row / rows_per_group);
+        const float* sc = scale_shift + ((long)g * 2) * C + cvi * VEC;
+        float v[VEC], r[VEC];
+        Act<T>::load(x + i * VEC, v);
+        if (res) Act<T>::load(res + i * VEC, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float o = v[k] * sc[k] + sc[C + k];
+            if (res) o += r[k];
+            if (relu) o = fmaxf(o, 0.f);
+            v[k] = o;
+        }
+        Act<T>::store(y + i * VEC, v);
+    }
+}
+
+// backward, stage 1: per (group, chunk, channel) sums of g and g*xhat with g = dy * [y > 0]
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* dy, const T* y, const T* x,
+                                                              const float* save_mean, const float* save_invstd,
+                                                              float* partial, int rows_per_group, int C,
+                                                              int rows_per_chunk, int nchunk, int relu) {
+    constexpr int VEC = Act<T>::VEC;
+    __shared__ float s1s[256 * VEC], s2s[256 * VEC];
+    const int CV = C / VEC, RL = 256 / CV;
+    const int cvi = threadIdx.x % CV, rl = threadIdx.x / CV;
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk;
+    const int nrows = min(rows_per_chunk, rows_per_group - r0);
+    const long off0 = ((long)g * rows_per_group + r0) * C + cvi * VEC;
+    float mean[VEC], istd[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        mean[i] = save_mean[(long)g * C + cvi * VEC + i];
+        istd[i] = save_invstd[(long)g * C + cvi * VEC + i];
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    for (int r = rl; r < nrows; r += RL) {
+        float gv[VEC], yv[VEC], xv[VEC];
+        const long o = off0 + (long)r * C;
+        Act<T>::load(dy + o, gv);
+        Act<T>::load(x + o, xv);
+        if (relu) Act<T>::load(y + o, yv);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float gm = gv[i];
+            if (relu && !(yv[i] > 0.f)) gm = 0.f;
+            s1[i] += gm;
+            s2[i] += gm * (xv[i] - mean[i]) * istd[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s1s[threadIdx.x * VEC + i] = s1[i]; s2s[threadIdx.x * VEC + i] = s2[i]; }
+    __syncthreads();
+    for (int step = RL >> 1; step > 0; step >>= 1) {
+        if (rl < step) {
+            const int o = threadIdx.x + step * CV;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                s1s[threadIdx.x * VEC + i] += s1s[o * VEC + i];
+                s2s[threadIdx.x * VEC + i] += s2s[o * VEC + i];
+            }
+        }
+        __syncthreads();
+    }
+    if (rl == 0) {
+        float* p = partial + ((long)(g * nchunk + chunk) * 2) * C + cvi * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { p[i] = s1s[threadIdx.x * VEC + i]; p[C + i] = s2s[threadIdx.x * VEC + i]; }
+    }
+}
+
+// backward, stage 2: coef[g][0][c] = gamma*invstd, [1] = S1/n, [2] = S2/n ; dgamma = S2, dbeta = S1
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* partial, int nchunk, int C,
+                                                                int rows_per_group, const float* gamma,
+                                                                const float* save_invstd, float* coef,
+                                                                float* dgamma, float* dbeta) {
+    __shared__ float a1[256], a2[256];
+    const int g = blockIdx.y;
+    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        for (int ch = lane8; ch < nchunk; ch += 8) {
+            const float* p = partial + ((long)(g * nchunk + ch) * 2) * C + c;
+            s1 += p[0]; s2 += p[C];
+        }
+    }
+    a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int step = 4; step > 0; step >>= 1) {
+        if (lane8 < step) { a1[threadIdx.x] += a1[threadIdx.x + step * 32]; a2[threadIdx.x] += a2[threadIdx.x + step * 32]; }
+        __syncthreads();
+    }
+    if (lane8 == 0 && c < C) {
+        const float n = (float)rows_per_group;
+        const float ga = gamma ? gamma[c] : 1.f;
+        coef[((long)g * 3) * C + c] = ga * save_invstd[(long)g * C + c];
+        coef[((long)g * 3 + 1) * C + c] = a1[threadIdx.x] / n;
+        coef[((long)g * 3 + 2) * C + c] = a2[threadIdx.x] / n;
+        if (dgamma) dgamma[c] = a2[threadIdx.x];
+        if (dbeta) dbeta[c] = a1[threadIdx.x];
+    }
+}
+
+// backward, stage 3: dx = a * (g - c1 - xhat * c2) ; dresidual = g
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* dy, const T* y, const T* x, T* dx, T* dres,
+                                                             const float* save_mean, const float* save_invstd,
+                                                             const float* coef, int rows_per_group, int C,
+                                                             long nvec, int relu) {
+    constexpr int VEC = Act<T>::VEC;
+    const int CV = C / VEC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / CV;
+        const int c0 = (int)(i % CV) * VEC;
+        const int g = (int)(row / rows_per_group);
+        const float* cf = coef + ((long)g * 3) * C + c0;
+        const float* mp = save_mean + (long)g * C + c0;
+        const float* ip = save_invstd + (long)g * C + c0;
+        float gv[VEC], yv[VEC], xv[VEC], o[VEC];
+        Act<T>::load(dy + i * VEC, gv);
+        Act<T>::load(x + i * VEC, xv);
+        if (relu) Act<T>::load(y + i * VEC, yv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float gm = gv[k];
+            if (relu && !(yv[k] > 0.f)) gm = 0.f;
+            gv[k] = gm;
+            const float xhat = (xv[k] - mp[k]) * ip[k];
+            o[k] = cf[k] * (gm - cf[C + k] - xhat * cf[2 * C + k]);
+        }
+        Act<T>::store(dx + i * VEC, o);
+        if (dres) Act<T>::store(dres + i * VEC, gv);
+    }
+}
+
+}  // namespace dvae

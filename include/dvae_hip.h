@@ -1,0 +1,173 @@
+/*
+ * dvae_hip.h -- C ABI of libdvae_hip.so, the MI355X (gfx950) kernels of the D-VAE hot path.
+ *
+ * The reference (yuyi-sd/D-VAE) is pure PyTorch and has no plugin ABI of its own: the seam this
+ * library replaces is the set of ATen ops that ResNetDVAE.forward, VAE_Trainer.train_batch and the
+ * epoch-0 branch of Trainer.train dispatch to.  Each entry point below names the reference lines
+ * whose arithmetic it performs.
+ *
+ * Conventions
+ *  - Every pointer is a device pointer owned by the caller (torch tensors' data_ptr()).  The library
+ *    never allocates, frees or synchronises; every launch is asynchronous on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream).
+ *  - Activations ("act" tensors) are NHWC with the channel count padded to dvae_act_channels(C)
+ *    (a power of two >= 4); pad channels hold zeros.  Element type is selected by `dtype`
+ *    (DVAE_F32 or DVAE_BF16); reductions, statistics, losses, gradients of parameters and the
+ *    optimiser state are always fp32.
+ *  - Parameters and their gradients keep the reference's layouts (Conv2d [Cout,Cin,kh,kw],
+ *    ConvTranspose2d [Cin,Cout,kh,kw], fp32); dvae_conv_pack produces the GEMM operand images.
+ *  - Return value: 0 on success, a negative DVAE_E* code otherwise; dvae_last_error() gives the
+ *    message of the calling thread's last failure.
+ */
+#ifndef DVAE_HIP_H
+#define DVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVAE_F32 0
+#define DVAE_BF16 1
+
+#define DVAE_OK 0
+#define DVAE_EINVAL (-1)   /* bad descriptor / unsupported shape */
+#define DVAE_EDTYPE (-2)   /* unsupported dtype */
+#define DVAE_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after a launch */
+#define DVAE_EWORKSPACE (-4) /* workspace too small */
+
+#define DVAE_OP_FWD 0
+#define DVAE_OP_DGRAD 1
+
+/* One nn.Conv2d / nn.ConvTranspose2d as the reference constructs it
+ * (configs/models/resnet.py:12-24, :1964, :2008-2050).  H, W are the spatial dims of the module's
+ * input; square kernels, symmetric padding, dilation 1, groups 1. */
+typedef struct dvae_conv_desc {
+    int32_t B, H, W;
+    int32_t Cin, Cout;        /* module in_channels / out_channels (logical, unpadded) */
+    int32_t kh, kw, stride, pad;
+    int32_t transposed;       /* 0 = Conv2d, 1 = ConvTranspose2d */
+} dvae_conv_desc;
+
+/* Fused epilogue of a forward conv: y = act( acc * scale[c] + shift[c] + residual ).
+ * scale == NULL means 1, shift == NULL means 0 (a conv bias is passed as shift). */
+typedef struct dvae_epilogue {
+    const float* scale;       /* [Cout] or NULL */
+    const float* shift;       /* [Cout] or NULL */
+    const void* residual;     /* act tensor shaped like the output, or NULL */
+    int32_t relu;
+    int32_t out_f32;          /* write fp32 even when dtype is bf16 (mu / log_var) */
+} dvae_epilogue;
+
+const char* dvae_version(void);
+const char* dvae_last_error(void);
+int dvae_act_channels(int C);
+
+/* ---- layout conversion at the module boundary ------------------------------------------------
+ * ToTensor (uint8 HWC -> float CHW / 255, main_vae_disentangle.py:409) and NCHW <-> NHWC. */
+int dvae_u8_to_act(const uint8_t* u8_nhwc, const int32_t* index /* [B] or NULL */, int64_t first,
+                   void* act, int B, int HW, int dtype, void* stream);
+int dvae_nchw_to_act(const float* nchw, void* act, int B, int C, int H, int W, int dtype, void* stream);
+int dvae_act_to_nchw(const void* act, float* nchw, int B, int C, int H, int W, int act_channels,
+                     int channel_offset, int act_is_f32, int dtype, void* stream);
+
+/* ---- convolutions (aten::conv2d / aten::conv_transpose2d and their autograd formulas) --------
+ * resnet.py:27-29, :2140, :2245-2246, :2199, :2012-2023, :2034-2045. */
+size_t dvae_conv_packed_elems(const dvae_conv_desc* d, int op);
+int dvae_conv_pack(const float* w_ref, void* w_packed, const dvae_conv_desc* d, int op, int dtype, void* stream);
+int dvae_conv_fwd(const void* x, const void* w_packed_fwd, const dvae_epilogue* ep, void* y,
+                  const dvae_conv_desc* d, int dtype, void* stream);
+int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int accumulate,
+                    const dvae_conv_desc* d, int dtype, void* stream);
+size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);
+int dvae_conv_wgrad(const void* x, const void* dy, float* dw_ref, float* db_ref /* or NULL */,
+                    void* workspace, size_t workspace_bytes, const dvae_conv_desc* d, int dtype, void* stream);
+
+/* ---- BatchNorm2d (+ residual add) + ReLU  (resnet.py:27-30) and InstanceNorm2d + ReLU
+ * (resnet.py:2014-2015, :2019-2020): one family of kernels over `groups` row groups of
+ * `rows_per_group` NHWC rows each (BatchNorm: 1 group of B*H*W rows; InstanceNorm: B groups of H*W).
+ * save_mean / save_invstd / scale / shift are [groups][C] fp32. */
+size_t dvae_norm_workspace_bytes(int groups, int rows_per_group, int C);
+int dvae_norm_fwd_train(const void* x, const void* residual, void* y,
+                        const float* gamma, const float* beta,          /* NULL for InstanceNorm */
+                        float* running_mean, float* running_var,        /* NULL for InstanceNorm */
+                        float* save_mean, float* save_invstd,
+                        void* workspace, size_t workspace_bytes,
+                        int groups, int rows_per_group, int C, int relu,
+                        float momentum, float eps, int dtype, void* stream);
+int dvae_bn_fwd_eval(const void* x, const void* residual, void* y,
+                     const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     float* scale_shift /* [2][C] scratch */, int rows, int C, int relu, float eps,
+                     int dtype, void* stream);
+/* eval-mode BatchNorm folded to a per-channel scale/shift for dvae_conv_fwd's epilogue */
+int dvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float* scale, float* shift, int C, float eps, void* stream);
+int dvae_norm_bwd(const void* dy, const void* y, const void* x,
+                  void* dx, void* dresidual /* or NULL: receives the ReLU-masked dy */,
+                  const float* gamma /* NULL for InstanceNorm */,
+                  const float* save_mean, const float* save_invstd,
+                  float* dgamma, float* dbeta /* NULL for InstanceNorm */,
+                  void* workspace, size_t workspace_bytes,
+                  int groups, int rows_per_group, int C, int relu, int dtype, void* stream);
+
+/* ---- class embedding of decoder_p's input (resnet.py:2211-2221) ------------------------------ */
+int dvae_emb_add_fwd(const float* emb, const int64_t* y, const void* add /* or NULL */, void* out,
+                     int B, int HW, int C, int spatial, int dtype, void* stream);
+int dvae_emb_bwd(const void* dout, const int64_t* y, float* demb, int B, int HW, int C,
+                 int num_classes, int spatial, int dtype, void* stream);
+
+/* ---- reparameterise + per-latent KL + rate constraint ---------------------------------------
+ * resnet.py:2257-2259 and main_vae_disentangle.py:204-205.  mulv is fp32 [rows][2L]: mu in
+ * columns [0,L), log_var in [L,2L).  eps is fp32 [rows][L]. */
+int dvae_philox_normal(float* out, const int32_t* image_index /* [B] or NULL */, int64_t first_image,
+                       int B, int per_image, uint64_t seed, uint32_t stream_id, void* stream);
+int dvae_reparam_kl_fwd(const float* mulv, const float* eps, void* z1, float* kl_partial /* [DVAE_NPARTIAL] */,
+                        int rows, int L, int dtype, void* stream);
+int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal,
+                        void* dmulv, int rows, int L, int dtype, void* stream);
+
+/* ---- reconstruction losses (main_vae_disentangle.py:190-192, :205-207) -----------------------
+ * rec_pre, p, x are act tensors with 3 logical channels; rec = sigmoid(rec_pre) is written fp32. */
+#define DVAE_NPARTIAL 1024
+#define DVAE_SCAL_LOSS 0
+#define DVAE_SCAL_LOSS_REC 1
+#define DVAE_SCAL_LOSS_REC_P 2
+#define DVAE_SCAL_LOSS_P 3
+#define DVAE_SCAL_KLD 4
+#define DVAE_SCAL_GATE_KL 5
+#define DVAE_SCAL_GATE_P 6
+#define DVAE_SCAL_GRAD_NORM 7
+#define DVAE_SCAL_C_REC 8     /* 2 / (B*3*H*W) */
+#define DVAE_SCAL_C_P 9       /* gate_p * 2 / (B*3*H*W) */
+#define DVAE_SCAL_C_KL 10     /* gate_kl * kld_weight / rows */
+#define DVAE_SCAL_COUNT 16
+int dvae_recon_loss_fwd(const void* rec_pre, const void* p, const void* x, float* rec /* fp32 act */,
+                        float* partial /* [3][DVAE_NPARTIAL] */, int npix, int dtype, void* stream);
+/* partial sums -> sums[4] = { sum (rec-x)^2, sum (clamp(rec+p)-x)^2, sum p^2, sum_rows KL } */
+int dvae_loss_reduce(const float* recon_partial, const float* kl_partial, float* sums, void* stream);
+/* sums (possibly summed over ranks) -> scal[DVAE_SCAL_COUNT]; n_elem = B*3*H*W and rows = B*h*w over
+ * the ranks that contributed to sums; local_* are this rank's counts (gradient scaling). */
+int dvae_loss_gate(const float* sums, float* scal, double n_elem, double rows, double local_n_elem,
+                   double local_rows, float kld_target, float kld_weight, int epoch_gt_10, void* stream);
+int dvae_recon_loss_bwd(const float* rec, const void* p, const void* x, const float* scal,
+                        void* d_rec_pre, void* d_p, int npix, int dtype, void* stream);
+
+/* ---- purification epilogue (main_vae_disentangle.py:62, :65, :67) ----------------------------
+ * v = clamp(a - b, 0, 1) (b may be NULL); u8 = trunc(255 * v) stored HWC at image `first`+i (or
+ * index[i]); v itself is optionally stored as the next pass's input. */
+int dvae_purify_quant(const void* a, const void* b, int a_is_f32, void* v_out /* or NULL */,
+                      uint8_t* out_u8_nhwc /* or NULL */, int64_t first, int B, int HW, int dtype, void* stream);
+
+/* ---- clip_grad_norm_ + Adam (main_vae_disentangle.py:210-211, resnet18DVAE.yaml:21-23) -------
+ * hyper (device, fp32[8]): lr, beta1, beta2, eps, max_norm, grad_scale, steps_done, unused;
+ * steps_done is incremented on the device after the update (graph-replay friendly). */
+int dvae_sqnorm_partial(const float* g, int64_t n, float* partial /* [DVAE_NPARTIAL] */, void* stream);
+int dvae_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float* hyper,
+                   const float* partial, float* scal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,168 @@
+"""Whole-path parity on the GPU (fp32 MFMA path): the HIP engine against the CPU oracle on the same
+seeded inputs and against the fixtures generated from the reference's own model code.
+
+Tolerances (fp32 both sides, different summation orders): activations 5e-5 of the tensor's scale,
+parameter gradients 5e-4 of the tensor's scale, scalars 1e-4 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dvae_oracle as O
+
+if torch.cuda.is_available():
+    import dvae_amd
+    from dvae_amd import _lib as L
+    from dvae_amd.engine import DVAEConfig, DVAEEngine
+    from util_gpu import from_act, rel_err, to_act
+
+SUB = 37
+VARIANTS = {
+    "main": (dict(), 2),
+    "use_y": (dict(use_y=True, spatial_emb=False), 2),
+    "classwise": (dict(sample_wise=False), 2),
+    "seb9": (dict(stem_end_block=9), 2),
+    "img64": (dict(image_size=64, spatial_emb=False, num_classes=200), 2),
+}
+SMALL_KL = {"fc_mu.weight": 0.02, "fc_mu.bias": 0.02, "fc_var.weight": 0.02, "fc_var.bias": 0.02}
+SMALL_P = {"decoder_p3.0.weight": 0.01, "decoder_p3.0.bias": 0.01}
+SCENARIOS = {
+    "open_e0_s0": (0, 0, None),
+    "closed_e0_s1": (0, 1, SMALL_KL),
+    "open_e11_s1": (11, 1, None),
+    "pclosed_e11_s0": (11, 0, {**SMALL_KL, **SMALL_P}),
+}
+NULL_GRAD_BIASES = ("decoder1.1.bias", "decoder2.0.bias", "decoder_p1.1.bias", "decoder_p2.0.bias")
+
+
+def make_engine(kw, B, overrides=None):
+    ocfg = O.DVAEConfig(**kw)
+    cfg = DVAEConfig(**kw)
+    eng = DVAEEngine(cfg, B, "cuda", L.F32)
+    p = O.recipe_params(ocfg, overrides)
+    eng.load_params(p)
+    return ocfg, eng, p
+
+
+def run_forward(eng, x, y, eps, train):
+    b = x.shape[0]
+    x0 = eng.input_from_nchw(x.cuda())
+    e = eng.eps_from_nchw(eps.cuda())
+    yd = y.cuda()
+    rec_pre, p = eng.forward(x0, yd, e, b, train)
+    rec = eng.loss_sums()
+    S, h, Ld = eng.S, eng.h, eng.Ld
+    mulv = eng.act("mulv", h, 2 * Ld, f32=True)
+    return {
+        "rec": from_act(rec[:b], 3), "perturbation": from_act(p[:b], 3),
+        "mu": from_act(mulv[:b, :, :, :Ld], Ld), "log_var": from_act(mulv[:b, :, :, Ld:], Ld),
+        "stem_out": from_act(eng._last["stem_out"][:b], 128), "z": from_act(eng.act("z", h, 128)[:b], 128),
+    }
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_forward_vs_oracle_and_golden(golden_dir, name, mode):
+    g = np.load(os.path.join(golden_dir, "g1_forward.npz"))
+    kw, B = VARIANTS[name]
+    ocfg, eng, p = make_engine(kw, B)
+    x, y, eps = O.make_inputs(ocfg, B)
+    with torch.no_grad():
+        stats = {}
+        ref = O.forward(p, ocfg, x, y, eps, mode == "train", stats)
+    out = run_forward(eng, x, y, eps, mode == "train")
+    for k in ("stem_out", "mu", "log_var", "z", "rec", "perturbation"):
+        assert rel_err(out[k], ref[k]) < 5e-5, k
+    pre = f"{name}.{mode}"
+    assert rel_err(out["rec"], g[pre + ".rec"]) < 5e-5
+    assert rel_err(out["perturbation"], g[pre + ".perturbation"]) < 5e-5
+    for nm in ("stem_out", "mu", "log_var", "z"):
+        assert rel_err(out[nm].reshape(-1)[::SUB], g[f"{pre}.{nm}.sub"]) < 5e-5, nm
+    if mode == "train":
+        for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.shortcut.1.running_mean", "layer2.0.bn2.running_var"):
+            assert rel_err(eng.buffers[k].cpu(), g[f"{pre}.stat.{k}"]) < 5e-5, k
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_losses_and_gradients(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "g2_loss_grads.npz"))
+    epoch, stage, ov = SCENARIOS[name]
+    ocfg, eng, p = make_engine({}, 4, ov)
+    x, y, eps = O.make_inputs(ocfg, 4)
+    target, weight = O.stage_constants(stage)
+    pc = {k: v.clone() for k, v in p.items()}
+    info, grads, _ = O.train_step(pc, ocfg, x, y, eps, {}, epoch, stage)
+
+    x0 = eng.input_from_nchw(x.cuda())
+    e = eng.eps_from_nchw(eps.cuda())
+    eng.forward(x0, y.cuda(), e, 4, True)
+    eng.loss_sums()
+    eng.loss_gate(epoch, target, weight)
+    eng.backward()
+    scal = eng.scal.cpu().numpy()
+    for k in ("loss", "loss_rec", "loss_rec_p", "loss_p", "kld"):
+        ref = float(g[f"{name}.{k}"])
+        assert abs(scal[L.SCAL[k]] - ref) <= 1e-4 * abs(ref) + 1e-7, (k, scal[L.SCAL[k]], ref)
+        assert abs(scal[L.SCAL[k]] - info[k]) <= 1e-4 * abs(info[k]) + 1e-7, k
+    for k, gref in grads.items():
+        got = eng.grad[k].cpu()
+        if k in NULL_GRAD_BIASES:
+            # true gradient is zero (InstanceNorm removes the constant): both sides are rounding noise
+            assert float(got.abs().max()) < 1e-6
+            continue
+        assert rel_err(got, gref) < 5e-4, k
+        ref = float(g[f"{name}.gnorm.{k}"])
+        assert abs(float(got.double().norm()) - ref) <= 5e-4 * ref + 1e-9, k
+    # clip + Adam: grad norm and one parameter update
+    eng.set_hyper(lr=5e-3)
+    eng.adam_step()
+    ref = float(g[f"{name}.grad_norm"])
+    assert abs(float(eng.scal[L.SCAL["grad_norm"]]) - ref) <= 2e-4 * ref
+    for k in ("conv1.weight", "fc_var.bias", "decoder1.0.weight", "emb_p.weight", "layer1.1.bn2.bias"):
+        assert rel_err(eng.param[k].cpu(), pc[k]) < 2e-4, k
+
+
+def test_three_step_trajectory(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_trajectory.npz"))
+    ocfg, eng, p = make_engine({}, 4)
+    target, weight = O.stage_constants(1)
+    eng.set_hyper(lr=5e-3, max_norm=5.0)
+    for step in range(3):
+        x, y, eps = O.make_inputs(ocfg, 4, seed=100 + step)
+        x0 = eng.input_from_nchw(x.cuda())
+        e = eng.eps_from_nchw(eps.cuda())
+        eng.train_step(x0, y.cuda(), e, 4, 11, target, weight)
+        scal = eng.scal.cpu().numpy()
+        for k in ("loss", "loss_rec", "loss_rec_p", "loss_p", "kld", "grad_norm"):
+            ref = float(g[f"step{step}.{k}"])
+            assert abs(scal[L.SCAL[k]] - ref) <= 5e-4 * abs(ref), (step, k, scal[L.SCAL[k]], ref)
+        for k in O.param_shapes(ocfg):
+            if k in NULL_GRAD_BIASES:
+                continue
+            t = eng.buffers[k] if O.is_buffer(k) else eng.param[k]
+            ref = float(g[f"step{step}.pl2.{k}"])
+            assert abs(float(t.double().norm()) - ref) <= 5e-4 * ref, (step, k)
+    assert float(eng.hyper[6]) == 3.0
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_purification_vs_golden(golden_dir, stage):
+    g = np.load(os.path.join(golden_dir, "g4_purify.npz"))
+    ocfg, eng, p = make_engine({}, 8)
+    data, labels = g["data"], g["labels"]
+    N = data.shape[0]
+    eps_all = torch.randn(2, N, 256, 16, 16, generator=torch.Generator().manual_seed(99))
+    d_dev = torch.from_numpy(data).cuda()
+    out = torch.zeros_like(d_dev)
+    noise = torch.zeros(N, 3, 32, 32, device="cuda")
+    lab = torch.from_numpy(labels).cuda().long()
+    for lo in range(0, N, 8):
+        b = min(8, N - lo)
+        eng.purify_batch(d_dev, out, noise, lab, lo, b, stage, eps_nchw=(eps_all[0, lo:lo + b].cuda(), eps_all[1, lo:lo + b].cuda()))
+    assert rel_err(noise.cpu(), g[f"stage{stage}.noise"]) < 1e-4
+    diff = np.abs(out.cpu().numpy().astype(np.int32) - g[f"stage{stage}.u8"].astype(np.int32))
+    # truncation flips by one LSB wherever the fp32 value differs by an ulp across k/255
+    assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
