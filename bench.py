@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the D-VAE hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], synthetic): CIFAR-10-shape uint8 images resident in HBM,
+ResNet18DVAE(num_classes=10, stem_end_block=7, latent_dim=256), sample_wise / use_y=False /
+spatial_emb (the published script flags), random-init weights.
+
+One "step" = one stage-1 purification batch per GPU (two eval-mode forwards, clamp, uint8 quantise,
+main_vae_disentangle.py:59-69).  ``value`` = purified images/s over all ranks.  The D-VAE train step
+(main_vae_disentangle.py:180-211 without the model_c monitors) is timed in a second region of the
+same run and reported as ``train_images_per_sec`` (per-GPU batch 128, gradient all-reduce over RCCL).
+Purification shards by image index (no data-path collective inside the timed region; the all-gather
+of the purified shards happens once per pass and is timed separately as ``allgather_ms``).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import dvae_amd  # noqa: E402
+from dvae_amd import _lib as L  # noqa: E402
+from dvae_amd.engine import DVAEConfig, DVAEEngine  # noqa: E402
+
+FWD_MACS = 418_775_040           # one model_s forward, classifier head excluded (per image, 32x32)
+TRAIN_MACS = 1_254_555_648       # forward + dgrad + wgrad, no dgrad for conv1
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, gfx950
+CONV_PROBE = "layer1.0.conv1"    # 3x3 64->64 @ 32x32: the shape that carries most of the FLOPs
+CONV_PROBE_MACS = 64 * 64 * 9 * 32 * 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--purify-batch", type=int, default=1024)
+    ap.add_argument("--train-batch", type=int, default=128)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--images", type=int, default=50000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    return ap.parse_args()
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(t, world):
+    if world > 1:
+        x = torch.tensor([t], device="cuda", dtype=torch.float64)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        return float(x.item())
+    return t
+
+
+def cpu_baseline(n_images, stage=1):
+    """The CPU oracle (stock fp32 torch ops restating the reference) purifying a bounded sample."""
+    from oracle import dvae_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.DVAEConfig()
+    p = O.recipe_params(cfg)
+    g = torch.Generator().manual_seed(0)
+    data = torch.randint(0, 256, (n_images, 32, 32, 3), generator=g, dtype=torch.uint8).numpy()
+    labels = (torch.arange(n_images) % 10).numpy()
+    eps = lambda ps, lo, hi: torch.randn(hi - lo, 256, 16, 16, generator=g)   # noqa: E731
+    O.purify(p, cfg, data[:128], labels[:128], eps, stage, batch=128)          # warm-up
+    t0 = time.perf_counter()
+    O.purify(p, cfg, data, labels, eps, stage, batch=128)
+    dt = time.perf_counter() - t0
+    return {"value": n_images / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n_images} synthetic 32x32x3 images, stage-1 purification (2 forwards), batch 128, fp32 torch CPU"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dtype = L.F32 if a.dtype == "f32" else L.BF16
+    cfg = DVAEConfig()
+    torch.manual_seed(0)
+
+    # ---------------- purification: images resident in HBM, sharded by index -------------------
+    Bp = a.purify_batch
+    eng = DVAEEngine(cfg, max(Bp, a.train_batch), "cuda", dtype, seed=0)
+    init_params(eng)
+    n_local = max(Bp, (a.images + world - 1) // world)
+    g = torch.Generator(device="cuda").manual_seed(rank)
+    data = torch.randint(0, 256, (n_local, 32, 32, 3), generator=g, dtype=torch.uint8, device="cuda")
+    labels = (torch.arange(n_local, device="cuda") % 10).long()
+    out = torch.empty_like(data)
+    noise = torch.empty(n_local, 3, 32, 32, device="cuda")
+    nb = n_local // Bp
+
+    def purify_step(i):
+        eng.purify_batch(data, out, noise, labels, (i % nb) * Bp, Bp, 1)
+
+    for i in range(a.warmup):
+        purify_step(i)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    eng.probe = None
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        eng.probe = (CONV_PROBE, ev[i]) if i < len(ev) else None
+        purify_step(a.warmup + i)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    eng.probe = None
+    purify_ips = world * Bp * a.steps / dt
+    probe_ms = sorted(s.elapsed_time(e) for s, e in ev)
+    probe_avg = sum(probe_ms) / len(probe_ms)
+
+    # one all-gather of the purified shards (once per pass, outside the per-batch hot loop)
+    allgather_ms = None
+    if world > 1:
+        gathered = torch.empty(world * n_local, 32, 32, 3, dtype=torch.uint8, device="cuda")
+        barrier(world)
+        t1 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, out)
+        barrier(world)
+        allgather_ms = max_over_ranks((time.perf_counter() - t1) * 1e3, world)
+
+    # ---------------- train step -----------------------------------------------------------------
+    train_ips = train_ms = None
+    if not a.no_train:
+        Bt = a.train_batch
+        eng.set_hyper(lr=5e-3, max_norm=5.0, grad_scale=1.0 / world, steps_done=0)
+        allreduce = (lambda t: dist.all_reduce(t)) if world > 1 else None
+        idx = torch.randperm(n_local, device="cuda", dtype=torch.int64).to(torch.int32)
+
+        def train_step(i):
+            lo = (i * Bt) % (n_local - Bt)
+            sel = idx[lo:lo + Bt]
+            x0 = eng.input_from_u8(data, 0, Bt, index=sel)
+            eps = eng.eps_philox(Bt, index=sel, stream_id=100 + i)
+            eng.train_step(x0, labels[sel.long()], eps, Bt, 11, 3.0, 0.01, allreduce, world)
+
+        for i in range(a.warmup):
+            train_step(i)
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            train_step(a.warmup + i)
+        barrier(world)
+        dtt = max_over_ranks(time.perf_counter() - t0, world)
+        train_ips = world * Bt * a.steps / dtt
+        train_ms = dtt / a.steps * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    peak = PEAK_TFLOPS[a.dtype]
+    probe_tflops = 2.0 * CONV_PROBE_MACS * Bp / (probe_avg * 1e-3) / 1e12
+    res = {
+        "metric": "purified images/sec (node) + VAE train imgs/sec, CIFAR-10 shape",
+        "value": purify_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic uint8 CIFAR-shape images resident in HBM, random-init weights",
+        "config": {"workload": "CIFAR-10 shape 32x32x3, ResNet18DVAE(seb=7, latent=256), stage-1 purification "
+                               f"(2 eval forwards + clamp + uint8 quantise), {Bp} images/GPU/step, sharded by image index",
+                   "purify_batch_per_gpu": Bp, "train_batch_per_gpu": a.train_batch, "images_per_gpu": n_local},
+        "train_images_per_sec": train_ips, "train_ms_per_step": train_ms, "allgather_ms": allgather_ms,
+        "purify_tflops": 2.0 * 2 * FWD_MACS * purify_ips / 1e12,
+        "train_tflops": (2.0 * TRAIN_MACS * train_ips / 1e12) if train_ips else None,
+        "roofline": {"bound": "mfma", "kernel": f"igemm_kernel ({CONV_PROBE}: 3x3 conv 64->64 @32x32, {Bp} images/launch)",
+                     "achieved": probe_tflops, "peak": peak, "unit": "TFLOP/s", "frac": probe_tflops / peak,
+                     "avg_launch_ms": probe_avg, "launches_timed": len(probe_ms), "traffic": None},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline(1024)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def init_params(eng):
+    """Random initialisation with torch's default distributions (kaiming_uniform(a=sqrt 5) for conv
+    weights and biases, N(0,1) embedding, BatchNorm gamma=1 beta=0), as the reference's modules do."""
+    import math
+    g = torch.Generator().manual_seed(0)
+    t = {}
+    for name, shape, _, _ in eng.layout:
+        if name == "emb_p.weight":
+            t[name] = torch.randn(shape, generator=g)
+        elif len(shape) == 4:
+            b = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+            t[name] = (torch.rand(shape, generator=g) * 2 - 1) * b
+        elif name.endswith(".bias") and ("bn" not in name and "shortcut.1" not in name):
+            wshape = dict((n, s) for n, s, _, _ in eng.layout)[name[:-4] + "weight"]
+            b = 1.0 / math.sqrt(wshape[1] * wshape[2] * wshape[3])
+            t[name] = (torch.rand(shape, generator=g) * 2 - 1) * b
+        elif name.endswith(".weight"):
+            t[name] = torch.ones(shape)
+        else:
+            t[name] = torch.zeros(shape)
+    eng.load_params(t, strict=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -213,6 +213,7 @@ class DVAEEngine:
         self._alloc_workspaces()
         self.fold_valid = False
         self.packed_valid = False
+        self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
 
     # ------------------------------------------------------------------------------------------
     def _desc(self, sp: ConvSpec, b: int) -> ConvDesc:
@@ -300,8 +301,13 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     def _conv(self, name, x, y, b, scale=None, shift=None, residual=None, relu=False, out_f32=False):
         ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32))
+        pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
+        if pr:
+            pr[1][0].record()
         check(self.lib.dvae_conv_fwd(ptr(x), ptr(self.packed[(name, L.OP_FWD)]), C.byref(ep), ptr(y),
                                      C.byref(self.desc(name, b)), self.dtype, L.stream()))
+        if pr:
+            pr[1][1].record()
 
     def _dgrad(self, name, dy, dx, b, accumulate=False):
         check(self.lib.dvae_conv_dgrad(ptr(dy), ptr(self.packed[(name, L.OP_DGRAD)]), ptr(dx), int(accumulate),

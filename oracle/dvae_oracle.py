@@ -154,6 +154,34 @@ BN_MOMENTUM = 0.1
 IN_EPS = 1e-5
 
 
+class _MaskedReLU(torch.autograd.Function):
+    """ReLU whose backward uses a caller-supplied mask instead of (output > 0).
+
+    A ReLU's gradient is discontinuous at 0: when a pre-activation is within rounding of zero, two
+    correct fp32 implementations may disagree on that one element's mask, and with small batches a
+    single flipped element moves some weight gradients by ~1e-2.  Gradient parity is therefore
+    checked with the masks of the implementation under test (each disagreement being verified to
+    sit at an ambiguous pre-activation), so every other source of error is held to a tight bound."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask.to(g.dtype), None
+
+
+def _relu(x, name, masks, pre):
+    if pre is not None:
+        pre[name] = x.detach()
+    if masks is not None and name in masks:
+        return _MaskedReLU.apply(x, masks[name])
+    return F.relu(x)
+
+
 def _bn(p, prefix, x, train: bool, new_stats: dict | None):
     """nn.BatchNorm2d: batch statistics in train mode (biased var normalises, unbiased var goes
     into the running estimate with momentum 0.1), running statistics in eval mode."""
@@ -169,49 +197,50 @@ def _bn(p, prefix, x, train: bool, new_stats: dict | None):
     return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
 
 
-def _basic_block(p, blk, x, train, new_stats):
+def _basic_block(p, blk, x, train, new_stats, masks=None, pre=None):
     """BasicBlock.forward, resnet.py:26-31."""
     stride = 2 if blk == "layer2.0" else 1
-    out = F.relu(_bn(p, blk + ".bn1", F.conv2d(x, p[blk + ".conv1.weight"], None, stride, 1), train, new_stats))
+    out = _relu(_bn(p, blk + ".bn1", F.conv2d(x, p[blk + ".conv1.weight"], None, stride, 1), train, new_stats),
+                blk + ".bn1.out", masks, pre)
     out = _bn(p, blk + ".bn2", F.conv2d(out, p[blk + ".conv2.weight"], None, 1, 1), train, new_stats)
     if (blk + ".shortcut.0.weight") in p:
         sc = _bn(p, blk + ".shortcut.1", F.conv2d(x, p[blk + ".shortcut.0.weight"], None, stride, 0), train, new_stats)
     else:
         sc = x
-    return F.relu(out + sc)
+    return _relu(out + sc, blk + ".out", masks, pre)
 
 
-def forward_stem(p, cfg, x, train, new_stats=None):
+def forward_stem(p, cfg, x, train, new_stats=None, masks=None, pre=None):
     """resnet.py:2139-2150."""
-    out = F.relu(_bn(p, "bn1", F.conv2d(x, p["conv1.weight"], None, 1, 1), train, new_stats))
+    out = _relu(_bn(p, "bn1", F.conv2d(x, p["conv1.weight"], None, 1, 1), train, new_stats), "bn1.out", masks, pre)
     for blk in block_names(cfg):
-        out = _basic_block(p, blk, out, train, new_stats)
+        out = _basic_block(p, blk, out, train, new_stats, masks, pre)
     return out
 
 
-def _decoder(p, d, z, sigmoid: bool):
+def _decoder(p, d, z, sigmoid: bool, masks=None, pre=None):
     """resnet.py:2011-2028 (decoder) / :2033-2050 (decoder_p, no sigmoid)."""
     h = F.conv_transpose2d(z, p[d + "1.0.weight"], p[d + "1.0.bias"], stride=2, padding=1)
     h = F.conv_transpose2d(h, p[d + "1.1.weight"], p[d + "1.1.bias"], stride=1, padding=1)
-    h = F.relu(F.instance_norm(h, eps=IN_EPS))
+    h = _relu(F.instance_norm(h, eps=IN_EPS), d + ".d3", masks, pre)
     h = F.conv_transpose2d(h, p[d + "2.0.weight"], p[d + "2.0.bias"], stride=1, padding=1)
-    h = F.relu(F.instance_norm(h, eps=IN_EPS))
+    h = _relu(F.instance_norm(h, eps=IN_EPS), d + ".d5", masks, pre)
     h = F.conv_transpose2d(h, p[d + "3.0.weight"], p[d + "3.0.bias"], stride=1, padding=1)
     return torch.sigmoid(h) if sigmoid else h
 
 
-def forward(p, cfg: DVAEConfig, x, y, eps, train: bool, new_stats: dict | None = None):
+def forward(p, cfg: DVAEConfig, x, y, eps, train: bool, new_stats: dict | None = None, masks=None, pre=None):
     """ResNetDVAE.forward (resnet.py:2203-2222) minus the unused classifier head.
 
     ``eps`` replaces the ``torch.randn_like`` draw of ``reparameterize`` (:2257-2259); the additive
     ``randn * 0.0`` on the input (:2206-2207) is a numeric no-op and is dropped.
     """
-    stem_out = forward_stem(p, cfg, x, train, new_stats)
+    stem_out = forward_stem(p, cfg, x, train, new_stats, masks, pre)
     mu = F.conv2d(stem_out, p["fc_mu.weight"], p["fc_mu.bias"])
     log_var = F.conv2d(stem_out, p["fc_var.weight"], p["fc_var.bias"])
     z1 = eps * torch.exp(0.5 * log_var) + mu
     z = F.conv2d(z1, p["post_conv.weight"], p["post_conv.bias"])
-    rec = _decoder(p, "decoder", z, True)
+    rec = _decoder(p, "decoder", z, True, masks, pre)
     if cfg.spatial_emb:
         emb = p["emb_p.weight"][y].reshape(stem_out.shape)
     else:
@@ -220,7 +249,7 @@ def forward(p, cfg: DVAEConfig, x, y, eps, train: bool, new_stats: dict | None =
         dec_in = emb + (stem_out if cfg.use_y else z)
     else:
         dec_in = emb
-    perturbation = _decoder(p, "decoder_p", dec_in, False)
+    perturbation = _decoder(p, "decoder_p", dec_in, False, masks, pre)
     return {"stem_out": stem_out, "mu": mu, "log_var": log_var, "z1": z1, "z": z,
             "rec": rec, "perturbation": perturbation}
 
@@ -280,14 +309,14 @@ def cosine_lr(base_lr: float, epoch: int, t_max: int, eta_min: float = 0.0):
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
 
 
-def train_step(p, cfg, x, y, eps, adam_state, epoch, stage, kd=3.0, lr=5e-3, grad_clip=5.0):
+def train_step(p, cfg, x, y, eps, adam_state, epoch, stage, kd=3.0, lr=5e-3, grad_clip=5.0, masks=None, pre=None):
     """One VAE_Trainer.train_batch without the model_c monitors.  Mutates ``p`` and ``adam_state``.
     Returns scalars and the clipped-before gradients for inspection."""
     target, weight = stage_constants(stage, kd)
     names = trainable_names(p)
     leaf = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
     new_stats = {}
-    out = forward(leaf, cfg, x, y, eps, True, new_stats)
+    out = forward(leaf, cfg, x, y, eps, True, new_stats, masks, pre)
     L = losses(out, x, epoch, target, weight)
     L["loss"].backward()
     grads = {k: leaf[k].grad.detach() for k in names if leaf[k].grad is not None}

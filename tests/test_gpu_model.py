@@ -17,7 +17,7 @@ if torch.cuda.is_available():
     import dvae_amd
     from dvae_amd import _lib as L
     from dvae_amd.engine import DVAEConfig, DVAEEngine
-    from util_gpu import from_act, rel_err, to_act
+    from util_gpu import from_act, l2_err, rel_err, to_act
 
 SUB = 37
 VARIANTS = {
@@ -63,6 +63,30 @@ def run_forward(eng, x, y, eps, train):
     }
 
 
+def engine_relu_masks(eng, b, ocfg, p, x, y, eps):
+    """(output > 0) of every ReLU as the engine computed it, after checking that each disagreement
+    with the oracle's own mask sits at a pre-activation within rounding of zero."""
+    names = [("bn1.out", 64)]
+    for blk in eng.blocks:
+        c = eng.specs[blk + ".conv1"].cout
+        names += [(blk + ".bn1.out", c), (blk + ".out", c)]
+    for d in ("decoder", "decoder_p"):
+        names += [(d + ".d3", 64), (d + ".d5", 32)]
+    pre = {}
+    with torch.no_grad():
+        O.forward(p, ocfg, x, y, eps, True, {}, None, pre)
+    masks, flips = {}, 0
+    for n, c in names:
+        m = from_act(eng._bufs[n][:b], c) > 0
+        bad = m != (pre[n] > 0)
+        if bad.any():
+            assert float(pre[n][bad].abs().max()) <= 2e-5 * float(pre[n].abs().max()), n
+        flips += int(bad.sum())
+        masks[n] = m
+    assert flips <= 8
+    return masks, flips
+
+
 @pytest.mark.parametrize("name", list(VARIANTS))
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_forward_vs_oracle_and_golden(golden_dir, name, mode):
@@ -93,12 +117,13 @@ def test_losses_and_gradients(golden_dir, name):
     ocfg, eng, p = make_engine({}, 4, ov)
     x, y, eps = O.make_inputs(ocfg, 4)
     target, weight = O.stage_constants(stage)
-    pc = {k: v.clone() for k, v in p.items()}
-    info, grads, _ = O.train_step(pc, ocfg, x, y, eps, {}, epoch, stage)
-
     x0 = eng.input_from_nchw(x.cuda())
     e = eng.eps_from_nchw(eps.cuda())
     eng.forward(x0, y.cuda(), e, 4, True)
+    # ReLU gradients are discontinuous at 0: differentiate the oracle with the engine's masks
+    masks, flips = engine_relu_masks(eng, 4, ocfg, p, x, y, eps)
+    pc = {k: v.clone() for k, v in p.items()}
+    info, grads, _ = O.train_step(pc, ocfg, x, y, eps, {}, epoch, stage, masks=masks)
     eng.loss_sums()
     eng.loss_gate(epoch, target, weight)
     eng.backward()
@@ -113,38 +138,59 @@ def test_losses_and_gradients(golden_dir, name):
             # true gradient is zero (InstanceNorm removes the constant): both sides are rounding noise
             assert float(got.abs().max()) < 1e-6
             continue
-        assert rel_err(got, gref) < 5e-4, k
+        assert rel_err(got, gref) < 1e-4, k
         ref = float(g[f"{name}.gnorm.{k}"])
-        assert abs(float(got.double().norm()) - ref) <= 5e-4 * ref + 1e-9, k
+        # the reference-generated fixture used its own masks: exact only when no ReLU flipped
+        assert abs(float(got.double().norm()) - ref) <= (1e-4 if flips == 0 else 5e-2) * ref + 1e-9, k
     # clip + Adam: grad norm and one parameter update
     eng.set_hyper(lr=5e-3)
     eng.adam_step()
     ref = float(g[f"{name}.grad_norm"])
-    assert abs(float(eng.scal[L.SCAL["grad_norm"]]) - ref) <= 2e-4 * ref
+    assert abs(float(eng.scal[L.SCAL["grad_norm"]]) - info["grad_norm"]) <= 1e-4 * info["grad_norm"]
+    assert abs(float(eng.scal[L.SCAL["grad_norm"]]) - ref) <= (2e-4 if flips == 0 else 2e-2) * ref
+    # Adam's first update is lr * g / (|g| + eps): an element whose gradient is rounding noise moves by
+    # +-lr with a noise-determined sign, so parameters are compared in L2 (the kernel itself is checked
+    # element-wise in test_gpu_ops.py::test_clip_adam_matches_torch).
     for k in ("conv1.weight", "fc_var.bias", "decoder1.0.weight", "emb_p.weight", "layer1.1.bn2.bias"):
-        assert rel_err(eng.param[k].cpu(), pc[k]) < 2e-4, k
+        assert l2_err(eng.param[k].cpu(), pc[k]) < 2e-3, k
 
 
 def test_three_step_trajectory(golden_dir):
+    """3 consecutive steps (clip 5.0, Adam lr 5e-3): against the oracle stepping with the engine's ReLU
+    masks (tight) and against the reference-generated fixture (loose: mask flips and Adam's
+    sign-like first steps amplify 1-ulp differences)."""
     g = np.load(os.path.join(golden_dir, "g3_trajectory.npz"))
     ocfg, eng, p = make_engine({}, 4)
     target, weight = O.stage_constants(1)
     eng.set_hyper(lr=5e-3, max_norm=5.0)
     for step in range(3):
+        # The oracle steps from the engine's own state (parameters, BatchNorm statistics, Adam moments):
+        # each step is checked tightly and earlier sign-noise of Adam does not accumulate into the masks.
+        po = {k: (eng.buffers[k] if O.is_buffer(k) else eng.param[k]).detach().cpu().clone() for k in O.param_shapes(ocfg)}
+        st = {n: {"step": step, "m": eng.M[o:o + k].view(sh).cpu().clone(), "v": eng.V[o:o + k].view(sh).cpu().clone()}
+              for n, sh, o, k in eng.layout}
         x, y, eps = O.make_inputs(ocfg, 4, seed=100 + step)
         x0 = eng.input_from_nchw(x.cuda())
         e = eng.eps_from_nchw(eps.cuda())
-        eng.train_step(x0, y.cuda(), e, 4, 11, target, weight)
+        eng.forward(x0, y.cuda(), e, 4, True)
+        masks, flips = engine_relu_masks(eng, 4, ocfg, po, x, y, eps)
+        info, _, _ = O.train_step(po, ocfg, x, y, eps, st, 11, 1, masks=masks)
+        eng.loss_sums()
+        eng.loss_gate(11, target, weight)
+        eng.backward()
+        eng.adam_step()
         scal = eng.scal.cpu().numpy()
         for k in ("loss", "loss_rec", "loss_rec_p", "loss_p", "kld", "grad_norm"):
+            assert abs(scal[L.SCAL[k]] - info[k]) <= 2e-4 * abs(info[k]), (step, k, scal[L.SCAL[k]], info[k])
             ref = float(g[f"step{step}.{k}"])
-            assert abs(scal[L.SCAL[k]] - ref) <= 5e-4 * abs(ref), (step, k, scal[L.SCAL[k]], ref)
+            assert abs(scal[L.SCAL[k]] - ref) <= 5e-3 * abs(ref), (step, k, scal[L.SCAL[k]], ref)
         for k in O.param_shapes(ocfg):
             if k in NULL_GRAD_BIASES:
                 continue
             t = eng.buffers[k] if O.is_buffer(k) else eng.param[k]
+            assert l2_err(t.cpu(), po[k]) < 3e-3, (step, k)
             ref = float(g[f"step{step}.pl2.{k}"])
-            assert abs(float(t.double().norm()) - ref) <= 5e-4 * ref, (step, k)
+            assert abs(float(t.double().norm()) - ref) <= 2e-3 * ref, (step, k)
     assert float(eng.hyper[6]) == 3.0
 
 

@@ -212,3 +212,92 @@ def test_quantiser_known_answers(golden_dir):
     out = torch.zeros(1, hw, 3, dtype=torch.uint8, device="cuda")
     L.check(lib.dvae_purify_quant(a.data_ptr(), None, 0, None, out.data_ptr(), 0, 1, hw, L.F32, L.stream()))
     assert np.array_equal(out[0, :, 1].cpu().numpy(), g["q"])
+
+
+@pytest.mark.parametrize("scale", [1.0, 100.0])
+def test_clip_adam_matches_torch(scale):
+    """clip_grad_norm_(5.0) + torch.optim.Adam(lr 5e-3) for 3 steps on a flat bucket; scale=100 forces
+    the clip branch.  Element-wise parity (gradients here are O(1), no near-zero sign ambiguity)."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(11)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=5e-3, weight_decay=0.0)
+    pd, md, vd = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    hyper = torch.tensor([5e-3, 0.9, 0.999, 1e-8, 5.0, 1.0, 0.0, 0.0], device="cuda")
+    partial = torch.zeros(L.NPARTIAL, device="cuda")
+    scal = torch.zeros(L.SCAL_COUNT, device="cuda")
+    for step in range(3):
+        gr = (torch.rand(n, generator=g) + 0.5) * torch.sign(torch.randn(n, generator=g)) * scale / n ** 0.5
+        ref.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+        opt.step()
+        gd = gr.cuda()
+        L.check(lib.dvae_sqnorm_partial(gd.data_ptr(), n, partial.data_ptr(), L.stream()))
+        L.check(lib.dvae_clip_adam(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, hyper.data_ptr(),
+                                   partial.data_ptr(), scal.data_ptr(), L.stream()))
+        assert abs(float(scal[L.SCAL["grad_norm"]]) - float(tn)) <= 1e-5 * float(tn)
+        assert rel_err(pd.cpu(), ref.detach()) < 1e-6
+    assert float(hyper[6]) == 3.0
+
+
+def test_reparam_kl_and_recon_loss_kernels():
+    """K3 / K4 against their torch formulas (main_vae_disentangle.py:190-192, :204; resnet.py:2257-2259)."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(21)
+    rows, Ld = 3 * 16 * 16, 256
+    mulv = torch.randn(rows, 2 * Ld, generator=g) * 0.7
+    eps = torch.randn(rows, Ld, generator=g)
+    mu, lv = mulv[:, :Ld].clone().requires_grad_(True), mulv[:, Ld:].clone().requires_grad_(True)
+    z1 = eps * torch.exp(0.5 * lv) + mu
+    kl_sum = (-0.5 * torch.sum(1 + lv - mu ** 2 - lv.exp(), dim=1)).sum()
+    dz = torch.randn(rows, Ld, generator=g)
+    ckl = 0.01 / rows
+    (z1 * dz).sum().backward(retain_graph=True)
+    (kl_sum * ckl).backward()
+    md, ed = mulv.cuda(), eps.cuda()
+    z1d = torch.empty(rows, Ld, device="cuda")
+    part = torch.zeros(L.NPARTIAL, device="cuda")
+    L.check(lib.dvae_reparam_kl_fwd(md.data_ptr(), ed.data_ptr(), z1d.data_ptr(), part.data_ptr(), rows, Ld, L.F32, L.stream()))
+    assert rel_err(z1d.cpu(), z1.detach()) < 1e-6
+    assert abs(float(part.double().sum()) - float(kl_sum)) <= 1e-5 * abs(float(kl_sum))
+    scal = torch.zeros(L.SCAL_COUNT, device="cuda")
+    scal[L.SCAL["c_kl"]] = ckl
+    dml = torch.empty(rows, 2 * Ld, device="cuda")
+    L.check(lib.dvae_reparam_kl_bwd(dz.cuda().data_ptr(), md.data_ptr(), ed.data_ptr(), scal.data_ptr(), dml.data_ptr(), rows, Ld,
+                                    L.F32, L.stream()))
+    assert rel_err(dml[:, :Ld].cpu(), mu.grad) < 2e-6
+    assert rel_err(dml[:, Ld:].cpu(), lv.grad) < 2e-6
+
+    npix = 2 * 32 * 32
+    rp = (torch.randn(npix, 3, generator=g) * 2).requires_grad_(True)
+    p = (torch.randn(npix, 3, generator=g) * 0.5).requires_grad_(True)
+    x = torch.rand(npix, 3, generator=g)
+    rec = torch.sigmoid(rp)
+    l0 = torch.nn.functional.mse_loss(rec, x)
+    l1 = torch.nn.functional.mse_loss((rec + p).clamp(0, 1), x)
+    l2 = torch.nn.functional.mse_loss(p, torch.zeros_like(p))
+    (l0 + l1 + l2).backward()
+
+    def pad(t):
+        o = torch.zeros(npix, 4)
+        o[:, :3] = t.detach()
+        return o.cuda()
+    rpd, pdv, xd = pad(rp), pad(p), pad(x)
+    recd = torch.empty(npix, 4, device="cuda")
+    part3 = torch.zeros(3 * L.NPARTIAL, device="cuda")
+    L.check(lib.dvae_recon_loss_fwd(rpd.data_ptr(), pdv.data_ptr(), xd.data_ptr(), recd.data_ptr(), part3.data_ptr(), npix, L.F32, L.stream()))
+    sums = torch.zeros(4, device="cuda")
+    L.check(lib.dvae_loss_reduce(part3.data_ptr(), part.data_ptr(), sums.data_ptr(), L.stream()))
+    L.check(lib.dvae_loss_gate(sums.data_ptr(), scal.data_ptr(), float(npix * 3), float(rows), float(npix * 3), float(rows),
+                               1.0, 0.01, 1, L.stream()))
+    sc = scal.cpu()
+    assert abs(float(sc[L.SCAL["loss_rec"]]) - float(l0)) < 1e-6 and abs(float(sc[L.SCAL["loss_rec_p"]]) - float(l1)) < 1e-6
+    assert abs(float(sc[L.SCAL["loss_p"]]) - float(l2)) < 1e-6
+    assert rel_err(recd[:, :3].cpu(), rec.detach()) < 1e-6
+    drp, dp = torch.empty(npix, 4, device="cuda"), torch.empty(npix, 4, device="cuda")
+    L.check(lib.dvae_recon_loss_bwd(recd.data_ptr(), pdv.data_ptr(), xd.data_ptr(), scal.data_ptr(), drp.data_ptr(), dp.data_ptr(),
+                                    npix, L.F32, L.stream()))
+    assert rel_err(drp[:, :3].cpu(), rp.grad) < 2e-6
+    assert rel_err(dp[:, :3].cpu(), p.grad) < 2e-6

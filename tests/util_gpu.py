@@ -20,7 +20,20 @@ def from_act(a, c):
     return a[..., :c].float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
+def _np(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().double().numpy()
+    return np.asarray(a, dtype=np.float64)
+
+
 def rel_err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a, b = _np(a), _np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def l2_err(a, b):
+    """||a - b||_2 / ||b||_2"""
+    a, b = _np(a), _np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))
