@@ -6,5 +6,9 @@ kernels behind the C ABI of ``include/dvae_hip.h`` (``lib/libdvae_hip.so``, buil
 from . import _lib
 from ._lib import BF16, F32
 from .engine import DVAEConfig, DVAEEngine
+from .model import ResNet18DVAE, ResNetDVAE
+from .optim import FusedAdam
+from .trainer import Trainer, VAE_Trainer, purify_dataset
 
-__all__ = ["_lib", "F32", "BF16", "DVAEConfig", "DVAEEngine"]
+__all__ = ["_lib", "F32", "BF16", "DVAEConfig", "DVAEEngine", "ResNet18DVAE", "ResNetDVAE", "FusedAdam", "Trainer",
+           "VAE_Trainer", "purify_dataset"]

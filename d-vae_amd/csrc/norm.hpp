@@ -18,12 +18,13 @@ struct NormGeom {
 static inline NormGeom norm_geom(int groups, int rows_per_group, int C) {
     NormGeom g;
     g.groups = groups; g.rows_per_group = rows_per_group; g.C = C;
-    // aim for >= ~1024 workgroups, chunks of >= 64 rows, at most 512 chunks per group
-    int want = (1024 + groups - 1) / groups;
-    if (want < 1) want = 1;
-    if (want > 512) want = 512;
-    int rpc = (rows_per_group + want - 1) / want;
-    if (rpc < 64) rpc = 64;
+    // Chunking depends on rows_per_group only -- never on the number of groups -- so that a group's
+    // statistics (InstanceNorm: one image) are bitwise independent of how many other images share the
+    // launch: chunks of >= 256 rows, at most 512 chunks per group.
+    int nchunk = (rows_per_group + 255) / 256;
+    if (nchunk > 512) nchunk = 512;
+    if (nchunk < 1) nchunk = 1;
+    int rpc = (rows_per_group + nchunk - 1) / nchunk;
     g.rows_per_chunk = rpc;
     g.nchunk = (rows_per_group + rpc - 1) / rpc;
     return g;

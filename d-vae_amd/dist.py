@@ -1,0 +1,87 @@
+"""Process-per-GPU data parallelism for the two shardable paths.
+
+The reference's only parallelism is single-process ``torch.nn.DataParallel``
+(/root/reference/main_vae_disentangle.py:426-428).  Here every GPU has its own process and the ranks
+meet through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests):
+
+* D-VAE training shards each global batch by sample; gradients are summed over ranks with ONE
+  all-reduce of the flat fp32 bucket per step (plus a 4-float all-reduce of the loss sums ahead of
+  the rate-constraint gate, so that the gate sees the global batch as DataParallel's does).
+* Purification shards the dataset by contiguous image-index ranges with no collective on the data
+  path; the uint8 shards (and perturbations) are all-gathered once per pass.  Reassembly is
+  concatenation in rank order, hence bit-identical to a single-GPU pass.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  No-op on one process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return world_info()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return world_info()
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous index range [lo, hi) of rank: ceil(n / world) images per rank, the tail rank(s) short."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def rank_batch_slice(global_batch_indices: torch.Tensor, rank: int, world: int):
+    """This rank's samples of one (already shuffled, drop_last'ed) global batch: a contiguous slice of
+    len(batch) / world samples.  Every rank derives the same permutation from the shared seed."""
+    b = global_batch_indices.numel()
+    if b % world:
+        raise ValueError(f"global batch {b} is not divisible by world size {world}")
+    per = b // world
+    return global_batch_indices[rank * per:(rank + 1) * per]
+
+
+def epoch_permutation(n: int, epoch: int, seed: int, device="cpu"):
+    """The shuffled sample order of one epoch, identical on every rank."""
+    g = torch.Generator().manual_seed(seed * 1_000_003 + epoch)
+    return torch.randperm(n, generator=g).to(device)
+
+
+def allreduce_sum_(t: torch.Tensor):
+    """In-place sum over ranks (identity on one process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_gather_shards(local: torch.Tensor, n: int) -> torch.Tensor:
+    """Reassemble per-rank shards made with ``shard_range`` into the full [n, ...] tensor on every rank.
+    Shards are padded to ceil(n / world) rows for the collective and the pad is cut off afterwards."""
+    rank, world = world_info()
+    if world == 1:
+        assert local.shape[0] == n
+        return local
+    per = (n + world - 1) // world
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out[:n]

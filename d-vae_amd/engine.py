@@ -201,6 +201,7 @@ class DVAEEngine:
                 self.packed[(name, op)] = torch.zeros(n, device=self.dev, dtype=self.tdt)
         # ---- scalars / partials ----------------------------------------------------------------
         self.hyper = torch.zeros(8, **f32)
+        self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if self.dev.type == "cuda" else torch.zeros(8)
         self.set_hyper(lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=5.0, grad_scale=1.0, steps_done=0)
         self.scal = torch.zeros(L.SCAL_COUNT, **f32)
         self.sums = torch.zeros(4, **f32)
@@ -234,7 +235,7 @@ class DVAEEngine:
             rows = B * (self.S * self.S if c == 64 else self.h * self.h)
             nb = max(nb, self.lib.dvae_norm_workspace_bytes(1, rows, c))
         for c in (64, 32):
-            nb = max(nb, self.lib.dvae_norm_workspace_bytes(B, self.S * self.S, c))
+            nb = max(nb, self.lib.dvae_norm_workspace_bytes(B, self.S * self.S, c))   # monotone in the group count
         self.wgrad_ws = torch.empty(wbytes // 4 + 16, device=self.dev, dtype=torch.float32)
         self.norm_ws = torch.empty(nb // 4 + 16, device=self.dev, dtype=torch.float32)
 
@@ -251,11 +252,16 @@ class DVAEEngine:
 
     # ------------------------------------------------------------------------------------------
     def set_hyper(self, **kw):
-        idx = dict(lr=0, beta1=1, beta2=2, eps=3, max_norm=4, grad_scale=5, steps_done=6)
-        h = self.hyper.cpu()
+        """Optimiser scalars live in device memory (graph replays read them there).  steps_done is
+        advanced on the device by every adam_step; set it here only to (re)start a run."""
+        idx = dict(lr=0, beta1=1, beta2=2, eps=3, max_norm=4, grad_scale=5)
+        h = self._hyper_host
         for k, v in kw.items():
-            h[idx[k]] = float(v)
-        self.hyper.copy_(h)
+            if k == "steps_done":
+                self.hyper[6:7].fill_(float(v))
+            else:
+                h[idx[k]] = float(v)
+        self.hyper[:6].copy_(h[:6], non_blocking=True)
 
     def load_params(self, tensors: dict, strict=True):
         """Copy reference-named tensors (CPU or GPU) into the bucket / BatchNorm buffers."""
@@ -386,25 +392,29 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     def forward(self, x0, y, eps, b, train: bool):
         """x0: input act [B,S,S,4]; y: int64 [b]; eps: fp32 act [B,h,h,L].  Leaves rec_pre / p (and
-        every intermediate needed by backward) in the engine's buffers and returns their names."""
+        every intermediate needed by backward) in the engine's buffers and returns them."""
+        stem_out = self.stem(x0, b, train)
+        _, _, z = self.latent(stem_out, eps, b)
+        rec_pre = self._decoder("decoder", z, b)
+        p = self.perturb(stem_out, z, y, b)
+        self._last = dict(b=b, x0=x0, y=y, eps=eps, stem_out=stem_out, train=train)
+        return rec_pre, p
+
+    def stem(self, x0, b, train: bool):
+        """resnet.py:2139-2150.  Train mode: conv -> batch-stat BatchNorm(+residual)+ReLU kernels.  Eval
+        mode: BatchNorm folded into the conv epilogue (scale/shift + residual + ReLU)."""
         if not self.packed_valid:
             self.pack_weights()
         if not train and not self.fold_valid:
             self.fold_bn()
-        S, h = self.S, self.h
-        rows_S, rows_h = b * S * S, b * h * h
-
-        def bn(name, x, out, rows, c, residual=None, relu=True):
-            self._bn_train(name, x, out, rows, c, residual, relu)
-
-        # --- stem ---
+        S = self.S
+        rows_S = b * S * S
+        a = self.act("bn1.out", S, 64)
         if train:
             c0 = self.act("conv1.out", S, 64)
             self._conv("conv1", x0, c0, b)
-            a = self.act("bn1.out", S, 64)
-            bn("bn1", c0, a, rows_S, 64)
+            self._bn_train("bn1", c0, a, rows_S, 64)
         else:
-            a = self.act("bn1.out", S, 64)
             sc, sh = self.bn_fold["bn1"]
             self._conv("conv1", x0, a, b, scale=sc, shift=sh, relu=True)
         for blk in self.blocks:
@@ -417,17 +427,17 @@ class DVAEEngine:
             if train:
                 c1 = self.act(blk + ".conv1.out", ho, co)
                 self._conv(blk + ".conv1", a, c1, b)
-                bn(blk + ".bn1", c1, t, rows, co)
+                self._bn_train(blk + ".bn1", c1, t, rows, co)
                 c2 = self.act(blk + ".conv2.out", ho, co)
                 self._conv(blk + ".conv2", t, c2, b)
                 if has_sc:
                     cs = self.act(blk + ".shortcut.0.out", ho, co)
                     self._conv(blk + ".shortcut.0", a, cs, b)
                     s = self.act(blk + ".shortcut.1.out", ho, co)
-                    bn(blk + ".shortcut.1", cs, s, rows, co, relu=False)
+                    self._bn_train(blk + ".shortcut.1", cs, s, rows, co, relu=False)
                 else:
                     s = a
-                bn(blk + ".bn2", c2, out, rows, co, residual=s)
+                self._bn_train(blk + ".bn2", c2, out, rows, co, residual=s)
             else:
                 sc, sh = self.bn_fold[blk + ".bn1"]
                 self._conv(blk + ".conv1", a, t, b, scale=sc, shift=sh, relu=True)
@@ -440,27 +450,33 @@ class DVAEEngine:
                 sc, sh = self.bn_fold[blk + ".bn2"]
                 self._conv(blk + ".conv2", t, out, b, scale=sc, shift=sh, residual=s, relu=True)
             a = out
-        stem_out = a
-        # --- latent ---
+        return a
+
+    def latent(self, stem_out, eps, b):
+        """encode (fc_mu|fc_var as one GEMM) -> reparameterise (+ KL partial sums) -> post_conv.
+        resnet.py:2197-2199, :2245-2246, :2257-2259."""
+        if not self.packed_valid:
+            self.pack_weights()
+        h = self.h
         mulv = self.act("mulv", h, 2 * self.Ld, f32=True)
         self._conv("fc", stem_out, mulv, b, shift=self.param["fc.bias"], out_f32=True)
         z1 = self.act("z1", h, self.Ld)
-        check(self.lib.dvae_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z1), ptr(self.kl_partial), rows_h, self.Ld,
+        check(self.lib.dvae_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z1), ptr(self.kl_partial), b * h * h, self.Ld,
                                            self.dtype, L.stream()))
         z = self.act("z", h, 128)
         self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"])
-        # --- decoders ---
-        rec_pre = self._decoder("decoder", z, b)
-        cfg = self.cfg
+        return mulv, z1, z
+
+    def perturb(self, stem_out, z, y, b):
+        """decoder_p(Embedding + stem_out | Embedding + z | Embedding), resnet.py:2211-2221."""
+        cfg, h = self.cfg, self.h
         ep = self.act("dec_p.in", h, 128)
         add = None
         if cfg.sample_wise:
             add = stem_out if cfg.use_y else z
         check(self.lib.dvae_emb_add_fwd(ptr(self.param["emb_p.weight"]), ptr(y), ptr(add), ptr(ep), b, h * h, 128,
                                         int(cfg.spatial_emb), self.dtype, L.stream()))
-        p = self._decoder("decoder_p", ep, b)
-        self._last = dict(b=b, x0=x0, y=y, eps=eps, stem_out=stem_out, train=train)
-        return rec_pre, p
+        return self._decoder("decoder_p", ep, b)
 
     def _decoder(self, d, zin, b):
         S = self.S
@@ -641,21 +657,23 @@ class DVAEEngine:
             allreduce(self.G)
         self.adam_step()
 
-    def purify_batch(self, data_u8, out_u8, noise_out, labels, first, b, stage, eps_nchw=None):
+    def purify_batch(self, data_u8, out_u8, noise_out, labels, first, b, stage, eps_nchw=None, global_first=None):
         """Purify images [first, first+b) of the resident uint8 set (main_vae_disentangle.py:59-69).
         Writes uint8 HWC into out_u8[first:first+b] and the (last) perturbation, NCHW fp32, into
-        noise_out[first:first+b].  ``eps_nchw``: optional (pass0, pass1) injected noise."""
+        noise_out[first:first+b].  ``eps_nchw``: optional (pass0, pass1) injected noise; otherwise the
+        noise is Philox keyed by the global image index ``global_first + i`` (shard-invariant)."""
         S = self.S
+        gf = first if global_first is None else global_first
         y = labels[first:first + b]
         x0 = self.input_from_u8(data_u8, first, b)
-        eps = self.eps_from_nchw(eps_nchw[0]) if eps_nchw is not None else self.eps_philox(b, first, stream_id=1)
+        eps = self.eps_from_nchw(eps_nchw[0]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=1)
         _, p = self.forward(x0, y, eps, b, False)
         if stage == 0:
             check(self.lib.dvae_purify_quant(ptr(x0), ptr(p), 0, None, ptr(out_u8), int(first), b, S * S, self.dtype, L.stream()))
         else:
             x1 = self.act("x1", S, 3)
             check(self.lib.dvae_purify_quant(ptr(x0), ptr(p), 0, ptr(x1), None, 0, b, S * S, self.dtype, L.stream()))
-            eps = self.eps_from_nchw(eps_nchw[1]) if eps_nchw is not None else self.eps_philox(b, first, stream_id=2)
+            eps = self.eps_from_nchw(eps_nchw[1]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=2)
             rec_pre, p = self.forward(x1, y, eps, b, False)
             rec = self.buf("rec", (self.B, S, S, 4), torch.float32)
             # sigmoid via the loss kernel's forward half (the sums are ignored here)

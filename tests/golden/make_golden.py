@@ -258,6 +258,20 @@ def gen_quant_kat():
     print("g5_quant_kat.npz", xs.size)
 
 
+def gen_state_dict_keys(ref):
+    """Names and shapes of ResNet18DVAE.state_dict() (161 entries, aliased decoder.* included)."""
+    import json
+    out = {}
+    for tag, seb, spatial in (("seb7_spatial", 7, True), ("seb9_flat", 9, False)):
+        net = ref.ResNet18DVAE(num_classes=10, stem_end_block=seb, latent_dim=256)
+        net.spatial_emb = spatial
+        net.set_spatial_emb()
+        out[tag] = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f)
+    print("state_dict_keys.json", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -267,3 +281,4 @@ if __name__ == "__main__":
     gen_trajectory(ref)
     gen_purify(ref)
     gen_quant_kat()
+    gen_state_dict_keys(ref)

@@ -1,0 +1,145 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/dvae_hip.h,
+the drop-in module reproduces the reference's state_dict layout, and the host logic (stage constants,
+loader semantics, shard arithmetic) behaves like the reference's."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dvae_amd
+from dvae_amd import _lib as L
+from dvae_amd import data as DD
+from dvae_amd import dist as D
+from dvae_amd.engine import DVAEConfig, conv_specs, param_layout
+from dvae_amd.model import ResNet18DVAE
+from dvae_amd.trainer import AverageMeter, log_display, random_crop_flip, stage_constants
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dvae_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(dvae_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 29
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(L.EXPORTS) == declared
+    assert lib.dvae_version().startswith(b"dvae_hip")
+    assert lib.dvae_act_channels(3) == 4 and lib.dvae_act_channels(64) == 64 and lib.dvae_act_channels(100) == 128
+
+
+def test_conv_plan_rejects_bad_descriptors():
+    import ctypes as C
+    lib = L.lib()
+    bad = L.ConvDesc(1, 32, 32, 64, 64, 5, 5, 1, 2, 0)       # 25 taps > 16
+    assert lib.dvae_conv_packed_elems(C.byref(bad), 0) == 0
+    rc = lib.dvae_conv_pack(None, None, C.byref(bad), 0, L.F32, None)
+    assert rc == -1 and b"conv desc" in lib.dvae_last_error()
+    ok = L.ConvDesc(2, 16, 16, 128, 64, 4, 4, 2, 1, 1)
+    assert lib.dvae_conv_packed_elems(C.byref(ok), 0) == 64 * 16 * 128
+    assert lib.dvae_conv_wgrad_workspace_bytes(C.byref(ok)) > 0
+
+
+@pytest.mark.parametrize("tag,seb,spatial", [("seb7_spatial", 7, True), ("seb9_flat", 9, False)])
+def test_state_dict_layout_matches_reference(golden_dir, tag, seb, spatial):
+    ref = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))[tag]
+    m = ResNet18DVAE(num_classes=10, stem_end_block=seb, latent_dim=256)
+    assert (m.sample_wise, m.use_y, m.spatial_emb) == (True, True, False)     # resnet.py:1974-1976
+    m.spatial_emb = spatial
+    m.set_spatial_emb()
+    mine = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    assert mine == ref and len(mine) == 161
+    sd = m.state_dict()
+    assert sd["decoder.0.0.weight"].data_ptr() == sd["decoder1.0.weight"].data_ptr()   # aliased entries
+
+
+def test_unsupported_stem_end_blocks_are_rejected():
+    for seb in (5, 11, 13, 15, 17):
+        with pytest.raises(ValueError):
+            ResNet18DVAE(10, seb, 256)
+
+
+def test_forward_without_gpu_fails_loudly():
+    m = ResNet18DVAE(10, 7, 256)
+    with pytest.raises(RuntimeError, match="libdvae_hip"):
+        m(torch.rand(2, 3, 32, 32), torch.zeros(2, dtype=torch.long))
+
+
+def test_param_layout_covers_the_live_parameters():
+    cfg = DVAEConfig()
+    n = sum(int(np.prod(s)) for _, s in param_layout(cfg))
+    # conv1+bn1+layer1 149 824; layer2[0] 230 144; fc_mu/fc_var/post_conv 98 944; decoders 2 x 187 395; emb_p 327 680
+    assert n == 149824 + 230144 + 98944 + 2 * 187395 + 327680
+    sp = conv_specs(cfg)
+    assert sp["decoder1.0"].hout == 32 and sp["layer2.0.conv1"].hout == 16 and sp["fc"].cout == 512
+
+
+def test_stage_constants_and_logging_helpers():
+    assert stage_constants(0, 3.0) == (1.0, 0.01)
+    assert stage_constants(1, 3.0) == (3.0, 0.01)
+    assert stage_constants(1, 0.5) == (0.5, 0.5)
+    m = AverageMeter()
+    m.update(2.0, 4)
+    m.update(4.0, 4)
+    assert m.avg == 3.0 and m.max == 4.0 and m.count == 8
+    s = log_display(epoch=1, global_step=7, time_elapse=0.5, loss=1.23456, lr=0.005)
+    assert s == "epoch=1\tglobal_step=7\tloss=1.2346\tlr=0.0050\ttime=2.00it/s"
+
+
+def test_device_loader_semantics_on_cpu():
+    ds = DD.synthetic_cifar(n=1000, seed=3)
+    gen = DD.DatasetGenerator(ds, train_batch_size=128, device="cpu")
+    train = gen.getDataLoader(train_shuffle=True, train_drop_last=True)["train_dataset"]
+    assert len(train) == 7                                   # 1000 // 128, as the VAE phase (drop_last)
+    seen = torch.cat(train.batches())
+    assert seen.numel() == 7 * 128 and seen.unique().numel() == seen.numel()
+    seq = gen.getDataLoader(train_shuffle=False, train_drop_last=False)["train_dataset"]
+    b = seq.batches()
+    assert len(b) == 8 and b[-1].numel() == 1000 - 7 * 128 and torch.equal(torch.cat(b), torch.arange(1000))
+    x, y = next(iter(seq))
+    assert x.shape == (128, 3, 32, 32) and x.dtype == torch.float32 and float(x.max()) <= 1.0
+    assert torch.equal(x[5], torch.from_numpy(ds.data[5]).permute(2, 0, 1).float() / 255)
+    # two ranks: disjoint halves of every global batch, same permutation
+    r0 = DD.DeviceLoader(ds, 64, True, True, "cpu", seed=1, rank=0, world=2).batches()
+    r1 = DD.DeviceLoader(ds, 64, True, True, "cpu", seed=1, rank=1, world=2).batches()
+    one = DD.DeviceLoader(ds, 128, True, True, "cpu", seed=1).batches()
+    for a, c, g in zip(r0, r1, one):
+        assert torch.equal(torch.cat([a, c]), g)
+
+
+def test_shard_ranges_partition_the_index_space():
+    for n in (0, 1, 7, 1000, 50000, 50001):
+        for w in (1, 2, 3, 4, 8):
+            r = [D.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in r) == (n + w - 1) // w
+    assert D.shard_range(50000, 3, 8) == (18750, 25000)
+
+
+def test_random_crop_flip_is_a_crop_of_the_padded_image():
+    x = torch.rand(16, 3, 32, 32)
+    torch.manual_seed(0)
+    y = random_crop_flip(x, 4)
+    assert y.shape == x.shape
+    xp = torch.nn.functional.pad(x, (4, 4, 4, 4))
+    for i in range(16):
+        found = False
+        for oy in range(9):
+            for ox in range(9):
+                w = xp[i, :, oy:oy + 32, ox:ox + 32]
+                if torch.equal(w, y[i]) or torch.equal(w.flip(-1), y[i]):
+                    found = True
+        assert found
+
+
+def test_purified_set_layout_roundtrip(tmp_path):
+    ds = DD.synthetic_cifar(n=64, seed=1)
+    DD.save_purified_numpy(ds, str(tmp_path))
+    d = np.load(tmp_path / "cifar10_data.npy")
+    t = np.load(tmp_path / "cifar10_target.npy")
+    assert d.dtype == np.uint8 and d.shape == (64, 32, 32, 3) and np.array_equal(d, ds.data) and np.array_equal(t, ds.targets)
