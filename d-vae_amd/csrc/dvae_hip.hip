@@ -96,7 +96,7 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     if (ep) e = *ep;
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
-    DVAE_FAIL(DVAE_EDTYPE, "conv_fwd: dtype %d not built", dtype);
+    return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
 }
 
 int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, const dvae_conv_desc* d, int dtype,
@@ -107,7 +107,7 @@ int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, co
     if (rc) return rc;
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 1, S(st));
-    DVAE_FAIL(DVAE_EDTYPE, "conv_dgrad: dtype %d not built", dtype);
+    return launch_igemm<bf16>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st));
 }
 
 size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d) {
@@ -126,7 +126,6 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     int rc = build_wgrad_plan(*d, dtype, W);
     if (rc) return rc;
     if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
-    if (dtype != DVAE_F32) DVAE_FAIL(DVAE_EDTYPE, "conv_wgrad: dtype %d not built", dtype);
     WgradArgs a;
     a.xg = d->transposed ? dy : x;
     a.d = d->transposed ? x : dy;
@@ -135,7 +134,10 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     a.CdS = W.CdS; a.ntaps = W.ntaps;
     memcpy(a.dy, W.dy, 16); memcpy(a.dx, W.dx, 16);
     a.M = W.M; a.chunk_rows = W.chunk_rows; a.Kpad = W.Kpad; a.CdPad = W.CdPad;
-    hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
+    if (dtype == DVAE_F32)
+        hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
+    else
+        hipLaunchKernelGGL(wgrad_kernel_bf16, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
     DVAE_CHECK_LAUNCH("wgrad");
     WreduceArgs r;
     r.ws = (const float*)ws; r.dw = dw; r.S = W.S; r.Kpad = W.Kpad; r.CdPad = W.CdPad; r.Cx = W.Cx;
@@ -149,8 +151,12 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
         const void* src = dy;
         const int CS = W.bias_from_gathered ? W.CxS : W.CdS;
         const int rows = W.bias_from_gathered ? W.B * W.Hx * W.Wx : W.M;
-        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(COLSUM_BLOCKS), dim3(256), 0, S(st), (const float*)src,
-                           part, rows, CS);
+        if (dtype == DVAE_F32)
+            hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(COLSUM_BLOCKS), dim3(256), 0, S(st), (const float*)src,
+                               part, rows, CS);
+        else
+            hipLaunchKernelGGL((colsum_partial_kernel<bf16>), dim3(COLSUM_BLOCKS), dim3(256), 0, S(st), (const bf16*)src,
+                               part, rows, CS);
         DVAE_CHECK_LAUNCH("colsum_partial");
         hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->Cout + 63) / 64), dim3(64), 0, S(st), part, db, COLSUM_BLOCKS,
                            CS, d->Cout);
@@ -294,11 +300,11 @@ int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, co
 }
 
 // ---------------------------------------------------------------------------------------------
-int dvae_recon_loss_fwd(const void* rec_pre, const void* p, const void* x, float* rec, float* partial, int npix,
+int dvae_recon_loss_fwd(const float* rec_pre, const float* p, const void* x, float* rec, float* partial, int npix,
                         int dtype, void* st) {
     if (npix <= 0) DVAE_FAIL(DVAE_EINVAL, "recon_loss: empty");
     DISPATCH_T(dtype, hipLaunchKernelGGL((recon_loss_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st),
-                                         (const T*)rec_pre, (const T*)p, (const T*)x, rec, partial, npix, act_c(3, dtype));)
+                                         (const float*)rec_pre, (const float*)p, (const T*)x, rec, partial, npix, act_c(3, dtype));)
     DVAE_CHECK_LAUNCH("recon_loss_fwd");
     return DVAE_OK;
 }
@@ -318,34 +324,33 @@ int dvae_loss_gate(const float* sums, float* scal, double n_elem, double rows, d
     return DVAE_OK;
 }
 
-int dvae_recon_loss_bwd(const float* rec, const void* p, const void* x, const float* scal, void* d_rec_pre, void* d_p,
+int dvae_recon_loss_bwd(const float* rec, const float* p, const void* x, const float* scal, void* d_rec_pre, void* d_p,
                         int npix, int dtype, void* st) {
     if (npix <= 0) DVAE_FAIL(DVAE_EINVAL, "recon_loss: empty");
     DISPATCH_T(dtype, hipLaunchKernelGGL((recon_loss_bwd_kernel<T>), dim3(grid_for(npix)), dim3(256), 0, S(st), rec,
-                                         (const T*)p, (const T*)x, scal, (T*)d_rec_pre, (T*)d_p, npix, act_c(3, dtype));)
+                                         (const float*)p, (const T*)x, scal, (T*)d_rec_pre, (T*)d_p, npix, act_c(3, dtype));)
     DVAE_CHECK_LAUNCH("recon_loss_bwd");
     return DVAE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-int dvae_purify_quant(const void* a, const void* b, int a_is_f32, void* v_out, uint8_t* u8, int64_t first, int B, int HW,
+int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out, uint8_t* u8, int64_t first, int B, int HW,
                       int dtype, void* st) {
     if (B <= 0 || HW <= 0) DVAE_FAIL(DVAE_EINVAL, "purify_quant: empty");
     const int CS = act_c(3, dtype);
     const int g = grid_for((long)B * HW);
-    if (dtype == DVAE_F32 || (a_is_f32 && dtype == DVAE_BF16)) {
-        if (dtype == DVAE_F32)
-            hipLaunchKernelGGL((purify_quant_kernel<float, float>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4,
-                               (const float*)b, CS, (float*)v_out, u8, (long)first, B, HW);
-        else
-            hipLaunchKernelGGL((purify_quant_kernel<float, bf16>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4,
-                               (const bf16*)b, CS, (bf16*)v_out, u8, (long)first, B, HW);
-    } else if (dtype == DVAE_BF16) {
-        hipLaunchKernelGGL((purify_quant_kernel<bf16, bf16>), dim3(g), dim3(256), 0, S(st), (const bf16*)a, CS,
-                           (const bf16*)b, CS, (bf16*)v_out, u8, (long)first, B, HW);
-    } else {
+    const float* bf = (const float*)b;
+    if (dtype == DVAE_F32)
+        hipLaunchKernelGGL((purify_quant_kernel<float, float>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4, bf, CS,
+                           (float*)v_out, u8, (long)first, B, HW);
+    else if (dtype == DVAE_BF16 && a_is_f32)
+        hipLaunchKernelGGL((purify_quant_kernel<float, bf16>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4, bf, CS,
+                           (bf16*)v_out, u8, (long)first, B, HW);
+    else if (dtype == DVAE_BF16)
+        hipLaunchKernelGGL((purify_quant_kernel<bf16, bf16>), dim3(g), dim3(256), 0, S(st), (const bf16*)a, CS, bf, CS,
+                           (bf16*)v_out, u8, (long)first, B, HW);
+    else
         DVAE_FAIL(DVAE_EDTYPE, "unknown dtype %d", dtype);
-    }
     DVAE_CHECK_LAUNCH("purify_quant");
     return DVAE_OK;
 }

@@ -185,15 +185,16 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const T* dz1, const
 // ------------------------------------------------------------------------------------------------
 // reconstruction losses.  One pixel (4 padded channels, 3 live) per thread per step.
 // ------------------------------------------------------------------------------------------------
+// rec_pre and p (the 3-channel decoder outputs) are always fp32 [npix][4]; x is an act tensor.
 template <typename T>
-__global__ __launch_bounds__(256) void recon_loss_fwd_kernel(const T* rec_pre, const T* p, const T* x, float* rec,
+__global__ __launch_bounds__(256) void recon_loss_fwd_kernel(const float* rec_pre, const float* p, const T* x, float* rec,
                                                              float* partial, int npix, int CS) {
     __shared__ float red[4];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
         float rp[4], pv[4], xv[4], r[4];
-        Act<T>::load4(rec_pre + i * CS, rp);
-        Act<T>::load4(p + i * CS, pv);
+        Act<float>::load4(rec_pre + i * 4, rp);
+        Act<float>::load4(p + i * 4, pv);
         Act<T>::load4(x + i * CS, xv);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -256,13 +257,13 @@ __global__ void loss_gate_kernel(const float* sums, float* scal, double n_elem, 
 // d rec = c (rec - x) + c (clamp(rec+p) - x) [0 <= rec+p <= 1] ; d p = c (clamp(rec+p) - x)[..] + c_p p
 // d rec_pre = d rec * rec (1 - rec)
 template <typename T>
-__global__ __launch_bounds__(256) void recon_loss_bwd_kernel(const float* rec, const T* p, const T* x, const float* scal,
+__global__ __launch_bounds__(256) void recon_loss_bwd_kernel(const float* rec, const float* p, const T* x, const float* scal,
                                                              T* d_rec_pre, T* d_p, int npix, int CS) {
     const float c = scal[DVAE_SCAL_C_REC], cp = scal[DVAE_SCAL_C_P];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
         float r[4], pv[4], xv[4], dr[4], dp[4];
         Act<float>::load4(rec + i * 4, r);
-        Act<T>::load4(p + i * CS, pv);
+        Act<float>::load4(p + i * 4, pv);
         Act<T>::load4(x + i * CS, xv);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -287,13 +288,14 @@ __global__ __launch_bounds__(256) void recon_loss_bwd_kernel(const float* rec, c
 // ------------------------------------------------------------------------------------------------
 // purification epilogue: v = clamp(a - b, 0, 1); u8 = trunc(255 * v) (fp32 product, as numpy does)
 // ------------------------------------------------------------------------------------------------
+// a: the image (act dtype) or rec (fp32 [.,4]); b: the perturbation, fp32 [.,4], or NULL.
 template <typename TA, typename T>
-__global__ void purify_quant_kernel(const TA* a, int CSA, const T* b, int CS, T* vout, uint8_t* u8, long first, int B, int HW) {
+__global__ void purify_quant_kernel(const TA* a, int CSA, const float* b, int CS, T* vout, uint8_t* u8, long first, int B, int HW) {
     const long total = (long)B * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float av[4], bv[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
         Act<TA>::load4(a + i * CSA, av);
-        if (b) Act<T>::load4(b + i * CS, bv);
+        if (b) Act<float>::load4(b + i * 4, bv);
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = fminf(fmaxf(av[c] - bv[c], 0.f), 1.f);
         v[3] = 0.f;

@@ -200,6 +200,19 @@ template <> struct Mfma<float> {
     }
 };
 
+template <> struct Mfma<bf16> {
+    // 128-byte K slab = 64 bf16.  v_mfma_f32_32x32x16_bf16: lane (r, h) supplies A[r][k = 8h + j] and
+    // B[k = 8h + j][r], j = 0..7: one 16-byte LDS read per operand per MFMA, four MFMAs per slab.
+    __device__ static inline void run(const unsigned char* arow, const unsigned char* brow, int h, f32x16& acc) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + 32 * s + 16 * h);
+            bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * s + 16 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+};
+
 template <typename T, int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     constexpr int BM = WGM * 32 * TM, BN = WGN * 32 * TN;
@@ -345,7 +358,8 @@ static int launch_igemm(const GemmPlan& P, const void* in, const void* wp, void*
     GemmArgs a;
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift; a.res = res;
     a.B = P.B; a.Hin = P.Hin; a.Win = P.Win; a.cg_log2 = P.cg_log2;
-    a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    // an fp32 output keeps the fp32 channel padding (>= 4) whatever the activation dtype is
+    a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
     int maxM = 0;
     for (int i = 0; i < 4; ++i) a.ph[i] = P.ph[i];
@@ -418,7 +432,7 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     W.CdPad = round_up(W.CdS, 64);
     const int tiles = (W.Kpad / 64) * (W.CdPad / 64);
     int S = 768 / tiles; if (S < 1) S = 1;
-    int chunk = round_up((W.M + S - 1) / S, 32); if (chunk < 32) chunk = 32;
+    int chunk = round_up((W.M + S - 1) / S, 64); if (chunk < 64) chunk = 64;
     W.chunk_rows = chunk;
     W.S = (W.M + chunk - 1) / chunk;
     return DVAE_OK;
@@ -494,6 +508,78 @@ __global__ __launch_bounds__(256) void wgrad_kernel_f32(const WgradArgs a) {
             const float av = As[(2 * s + h) * 64 + wi * 32 + r];
             const float bv = Ds[(2 * s + h) * 64 + wj * 32 + r];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* ws = a.ws + ((long)blockIdx.x * a.Kpad + kbase + wi * 32) * a.CdPad + cdbase + wj * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ws[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * a.CdPad] = acc[e];
+}
+
+// bf16: same decomposition; 64 pixels per LDS stage in [pixel][channel] order (192-byte rows: the four
+// rows of a transposed read land on disjoint bank quarters), operands fetched with ds_read_b64_tr_b16 so
+// that each lane receives 4 consecutive pixels of one channel = the k-contiguous MFMA fragment layout.
+__device__ inline bf16x8 tr_frag(const unsigned char* tile, int mrow0, int col0, int lane) {
+    constexpr int RS = 192;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, h = g >> 1;
+    const unsigned char* base = tile + (mrow0 + 8 * h + q) * RS + (col0 + 16 * (g & 1) + 4 * p) * 2;
+    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base));
+    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base + 4 * RS));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel_bf16(const WgradArgs a) {
+    constexpr int RS = 192, MS = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char As[MS * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Ds[MS * RS];
+    const int tid = threadIdx.x, kv = tid & 7, rl = tid >> 3;      // 8 x 16-byte vectors per 64-channel row
+    const int kbase = blockIdx.y * 64, cdbase = blockIdx.z * 64;
+    const int k = kbase + kv * 8;
+    const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
+    const bool tv = tap < a.ntaps;
+    const int dy = a.dy[tap & 15], dx = a.dx[tap & 15];
+    const int cd = cdbase + kv * 8;
+    const bool cv = cd < a.CdS;
+    const int mbeg = blockIdx.x * a.chunk_rows;
+    const int mend = min(a.M, mbeg + a.chunk_rows);
+    const bf16* xg = reinterpret_cast<const bf16*>(a.xg);
+    const bf16* dd = reinterpret_cast<const bf16*>(a.d);
+    u32x4 xr[2], dr[2];
+    auto load = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mb + rl + 32 * i;
+            u32x4 xv = {0u, 0u, 0u, 0u}, dv = {0u, 0u, 0u, 0u};
+            if (m < mend) {
+                const int x = m % a.Wg, t = m / a.Wg, y = t % a.Hg, b = t / a.Hg;
+                const int iy = y * a.SY + dy, ix = x * a.SX + dx;
+                if (tv && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
+                    xv = *reinterpret_cast<const u32x4*>(xg + (((long)((b * a.Hx + iy) * a.Wx + ix)) << a.cx_log2) + c);
+                if (cv) dv = *reinterpret_cast<const u32x4*>(dd + (long)m * a.CdS + cd);
+            }
+            xr[i] = xv; dr[i] = dv;
+        }
+    };
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (mbeg < mend) load(mbeg);
+    for (int mb = mbeg; mb < mend; mb += MS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(As + (rl + 32 * i) * RS + kv * 16) = xr[i];
+            *reinterpret_cast<u32x4*>(Ds + (rl + 32 * i) * RS + kv * 16) = dr[i];
+        }
+        __syncthreads();
+        if (mb + MS < mend) load(mb + MS);
+#pragma unroll
+        for (int s = 0; s < MS / 16; ++s) {
+            const bf16x8 av = tr_frag(As, 16 * s, wi * 32, lane);
+            const bf16x8 bv = tr_frag(Ds, 16 * s, wj * 32, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
         }
         __syncthreads();
     }

@@ -490,8 +490,8 @@ class DVAEEngine:
         self._conv(d + "2.0", d3, d4, b, shift=self.param[d + "2.0.bias"])
         d5 = self.act(d + ".d5", S, 32)
         self._in_fwd(d + ".in2", d4, d5, b, 32)
-        d6 = self.act(d + ".d6", S, 3)
-        self._conv(d + "3.0", d5, d6, b, shift=self.param[d + "3.0.bias"])
+        d6 = self.act(d + ".d6", S, 3, f32=True)       # rec_pre / perturbation stay fp32 on every path
+        self._conv(d + "3.0", d5, d6, b, shift=self.param[d + "3.0.bias"], out_f32=True)
         return d6
 
     # ------------------------------------------------------------------------------------------
@@ -502,7 +502,7 @@ class DVAEEngine:
         b = self._last["b"]
         S = self.S
         rec = self.buf("rec", (self.B, S, S, 4), torch.float32)
-        check(self.lib.dvae_recon_loss_fwd(ptr(self.act("decoder.d6", S, 3)), ptr(self.act("decoder_p.d6", S, 3)),
+        check(self.lib.dvae_recon_loss_fwd(ptr(self.act("decoder.d6", S, 3, f32=True)), ptr(self.act("decoder_p.d6", S, 3, f32=True)),
                                            ptr(self._last["x0"]), ptr(rec), ptr(self.recon_partial), b * S * S,
                                            self.dtype, L.stream()))
         check(self.lib.dvae_loss_reduce(ptr(self.recon_partial), ptr(self.kl_partial), ptr(self.sums), L.stream()))
@@ -530,7 +530,7 @@ class DVAEEngine:
             d_rec_pre = self.act("g.decoder.d6", S, 3)
             d_p = self.act("g.decoder_p.d6", S, 3)
             check(self.lib.dvae_recon_loss_bwd(ptr(self.buf("rec", (self.B, S, S, 4), torch.float32)),
-                                               ptr(self.act("decoder_p.d6", S, 3)), ptr(L_["x0"]), ptr(self.scal),
+                                               ptr(self.act("decoder_p.d6", S, 3, f32=True)), ptr(L_["x0"]), ptr(self.scal),
                                                ptr(d_rec_pre), ptr(d_p), b * S * S, self.dtype, st()))
         cfg = self.cfg
         z = self.act("z", h, 128)

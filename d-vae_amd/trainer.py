@@ -143,7 +143,7 @@ class VAE_Trainer:
         if model_c is not None and self.monitor_every and self.global_step % self.monitor_every == 0:
             S = eng.S
             rec = eng.to_nchw(eng.buf("rec", (eng.B, S, S, 4), torch.float32), b, 3, S)
-            pert = eng.to_nchw(eng.act("decoder_p.d6", S, 3), b, 3, S)
+            pert = eng.to_nchw(eng.act("decoder_p.d6", S, 3, f32=True), b, 3, S)
             self._monitor(images, labels, rec, pert, model_c, force=True)
         # statistics stay on the device; materialize() syncs once, at log time
         s = eng.scal.clone()

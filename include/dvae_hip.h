@@ -58,7 +58,7 @@ typedef struct dvae_epilogue {
     const float* shift;       /* [Cout] or NULL */
     const void* residual;     /* act tensor shaped like the output, or NULL */
     int32_t relu;
-    int32_t out_f32;          /* write fp32 even when dtype is bf16 (mu / log_var) */
+    int32_t out_f32;          /* write fp32 (channel padding of the fp32 rule) even when dtype is bf16: mu|log_var, rec_pre, p */
 } dvae_epilogue;
 
 const char* dvae_version(void);
@@ -129,7 +129,9 @@ int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, co
                         void* dmulv, int rows, int L, int dtype, void* stream);
 
 /* ---- reconstruction losses (main_vae_disentangle.py:190-192, :205-207) -----------------------
- * rec_pre, p, x are act tensors with 3 logical channels; rec = sigmoid(rec_pre) is written fp32. */
+ * rec_pre and p (the decoders' 3-channel outputs, written by dvae_conv_fwd with out_f32) are fp32
+ * [npix][4]; x is an act tensor; rec = sigmoid(rec_pre) is written fp32 [npix][4]; d_rec_pre / d_p are
+ * act tensors (operands of the transposed convs' gradients). */
 #define DVAE_NPARTIAL 1024
 #define DVAE_SCAL_LOSS 0
 #define DVAE_SCAL_LOSS_REC 1
@@ -143,7 +145,7 @@ int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, co
 #define DVAE_SCAL_C_P 9       /* gate_p * 2 / (B*3*H*W) */
 #define DVAE_SCAL_C_KL 10     /* gate_kl * kld_weight / rows */
 #define DVAE_SCAL_COUNT 16
-int dvae_recon_loss_fwd(const void* rec_pre, const void* p, const void* x, float* rec /* fp32 act */,
+int dvae_recon_loss_fwd(const float* rec_pre, const float* p, const void* x, float* rec,
                         float* partial /* [3][DVAE_NPARTIAL] */, int npix, int dtype, void* stream);
 /* partial sums -> sums[4] = { sum (rec-x)^2, sum (clamp(rec+p)-x)^2, sum p^2, sum_rows KL } */
 int dvae_loss_reduce(const float* recon_partial, const float* kl_partial, float* sums, void* stream);
@@ -151,13 +153,14 @@ int dvae_loss_reduce(const float* recon_partial, const float* kl_partial, float*
  * the ranks that contributed to sums; local_* are this rank's counts (gradient scaling). */
 int dvae_loss_gate(const float* sums, float* scal, double n_elem, double rows, double local_n_elem,
                    double local_rows, float kld_target, float kld_weight, int epoch_gt_10, void* stream);
-int dvae_recon_loss_bwd(const float* rec, const void* p, const void* x, const float* scal,
+int dvae_recon_loss_bwd(const float* rec, const float* p, const void* x, const float* scal,
                         void* d_rec_pre, void* d_p, int npix, int dtype, void* stream);
 
 /* ---- purification epilogue (main_vae_disentangle.py:62, :65, :67) ----------------------------
- * v = clamp(a - b, 0, 1) (b may be NULL); u8 = trunc(255 * v) stored HWC at image `first`+i (or
- * index[i]); v itself is optionally stored as the next pass's input. */
-int dvae_purify_quant(const void* a, const void* b, int a_is_f32, void* v_out /* or NULL */,
+ * v = clamp(a - b, 0, 1); a is the image (act tensor) or, with a_is_f32, rec (fp32 [npix][4]); b is the
+ * perturbation (fp32 [npix][4]) or NULL; u8 = trunc(255 * v) stored HWC at image `first`+i; v itself is
+ * optionally stored as the next pass's input (act tensor). */
+int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out /* or NULL */,
                       uint8_t* out_u8_nhwc /* or NULL */, int64_t first, int B, int HW, int dtype, void* stream);
 
 /* ---- clip_grad_norm_ + Adam (main_vae_disentangle.py:210-211, resnet18DVAE.yaml:21-23) -------

@@ -1,0 +1,162 @@
+"""bf16 MFMA path (bf16 activations / packed weights, fp32 accumulation, fp32 statistics, losses,
+gradients of parameters and optimiser state) against the fp32 references.
+
+Stated tolerance: bf16 keeps 8 significant bits (2^-9 = 2e-3 relative rounding per stored value), so
+conv outputs are held to 6e-3 of the tensor's scale (1e-4 with fp32 output), whole-network outputs to 6e-2
+in L2, loss scalars to 3e-2, the gradient bucket to cosine > 0.998 with the fp32 oracle (single tensors up to
+0.25 in L2 at batch 8: at initialisation the KL term dominates the stem gradient and BatchNorm's backward
+cancels most of it, which amplifies the bf16 rounding of the stored gradient maps), and purified uint8
+images to a mean difference < 0.75 LSB (> 98.5 % of pixels within 4 LSB) of the fp32 path."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dvae_oracle as O
+
+if torch.cuda.is_available():
+    import dvae_amd
+    from dvae_amd import _lib as L
+    from dvae_amd.engine import ConvSpec, DVAEConfig, DVAEEngine
+    from util_gpu import from_act, l2_err, rel_err, to_act
+
+CONVS = [
+    (3, 64, 3, 1, 1, False, 32, False),
+    (64, 64, 3, 1, 1, False, 32, False),
+    (64, 128, 3, 2, 1, False, 32, False),
+    (64, 128, 1, 2, 0, False, 32, False),
+    (128, 512, 1, 1, 0, False, 16, True),
+    (128, 64, 4, 2, 1, True, 16, True),
+    (64, 32, 3, 1, 1, True, 32, True),
+    (32, 3, 3, 1, 1, True, 32, True),
+    (64, 128, 3, 2, 1, False, 13, False),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_bf16(cfg):
+    cin, cout, k, stride, pad, tr, hin, bias = cfg
+    B = 3
+    lib = L.lib()
+    g = torch.Generator().manual_seed(hash(cfg) & 0xffff)
+    sp = ConvSpec("t", cin, cout, k, stride, pad, tr, hin, bias)
+    q = lambda t: t.bfloat16().float()      # noqa: E731  operands as the kernel sees them
+    w = q(torch.randn(sp.wshape, generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
+    bvec = torch.randn(cout, generator=g) if bias else None
+    x = q(torch.randn(B, cin, hin, hin, generator=g)).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, bvec, stride=stride, padding=pad) if tr else F.conv2d(x, w, bvec, stride=stride, padding=pad)
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    ho = y.shape[2]
+    d = L.ConvDesc(B, hin, hin, cin, cout, k, k, stride, pad, int(tr))
+    st = L.stream()
+    wdev = w.detach().cuda().contiguous()
+    pk = {}
+    for op in (L.OP_FWD, L.OP_DGRAD):
+        pk[op] = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), op), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_conv_pack(wdev.data_ptr(), pk[op].data_ptr(), C.byref(d), op, L.BF16, st))
+    xa = to_act(x.detach(), L.BF16)
+    ya = torch.full((B, ho, ho, L.act_channels(cout, L.BF16)), 7.0, device="cuda", dtype=torch.bfloat16)
+    bdev = bvec.cuda() if bias else None
+    ep = L.Epilogue(None, L.ptr(bdev), None, 0, 0)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk[L.OP_FWD].data_ptr(), C.byref(ep), ya.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(ya, cout), y.detach()) < 6e-3          # exact products, fp32 sums, one bf16 rounding of y
+    yf = torch.empty(B, ho, ho, L.act_channels(cout, L.F32), device="cuda")     # fp32 outputs use the fp32 channel padding
+    ep = L.Epilogue(None, L.ptr(bdev), None, 0, 1)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk[L.OP_FWD].data_ptr(), C.byref(ep), yf.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(yf, cout), y.detach()) < 1e-4          # fp32 output: only summation order differs
+    gya = to_act(gy, L.BF16)
+    dxa = torch.zeros(B, hin, hin, L.act_channels(cin, L.BF16), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_dgrad(gya.data_ptr(), pk[L.OP_DGRAD].data_ptr(), dxa.data_ptr(), 0, C.byref(d), L.BF16, st))
+    assert rel_err(from_act(dxa, cin), x.grad) < 6e-3
+    ws = torch.empty(lib.dvae_conv_wgrad_workspace_bytes(C.byref(d)) // 4 + 4, device="cuda")
+    dw = torch.full(sp.wshape, 9.0, device="cuda")
+    db = torch.full((cout,), 9.0, device="cuda") if bias else None
+    L.check(lib.dvae_conv_wgrad(xa.data_ptr(), gya.data_ptr(), dw.data_ptr(), L.ptr(db), ws.data_ptr(), ws.numel() * 4,
+                                C.byref(d), L.BF16, st))
+    assert rel_err(dw.cpu(), w.grad) < 1e-4                        # fp32 accumulation of exact bf16 products
+    if bias:
+        assert rel_err(db.cpu(), gy.sum(dim=(0, 2, 3))) < 1e-4
+
+
+def _engine(dtype, B, ov=None):
+    ocfg, cfg = O.DVAEConfig(), DVAEConfig()
+    eng = DVAEEngine(cfg, B, "cuda", dtype)
+    p = O.recipe_params(ocfg, ov)
+    eng.load_params(p)
+    return ocfg, eng, p
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_model_forward_bf16(train):
+    ocfg, eng, p = _engine(L.BF16, 4)
+    x, y, eps = O.make_inputs(ocfg, 4)
+    with torch.no_grad():
+        ref = O.forward(p, ocfg, x, y, eps, train, {})
+    x0 = eng.input_from_nchw(x.cuda())
+    e = eng.eps_from_nchw(eps.cuda())
+    rec_pre, pp = eng.forward(x0, y.cuda(), e, 4, train)
+    rec = eng.loss_sums()
+    mulv = eng.act("mulv", 16, 512, f32=True)
+    assert l2_err(from_act(rec[:4], 3), ref["rec"]) < 3e-2
+    assert l2_err(from_act(pp[:4], 3), ref["perturbation"]) < 6e-2
+    assert l2_err(from_act(mulv[:4, :, :, :256], 256), ref["mu"]) < 6e-2
+    assert l2_err(from_act(mulv[:4, :, :, 256:], 256), ref["log_var"]) < 6e-2
+
+
+def test_train_step_bf16_tracks_fp32():
+    """Losses and gradients of one step, bf16 engine vs the fp32 oracle (gate open, epoch 11, stage 1)."""
+    ocfg, eng, p = _engine(L.BF16, 8)
+    x, y, eps = O.make_inputs(ocfg, 8)
+    info, grads, _ = O.train_step({k: v.clone() for k, v in p.items()}, ocfg, x, y, eps, {}, 11, 1)
+    x0 = eng.input_from_nchw(x.cuda())
+    e = eng.eps_from_nchw(eps.cuda())
+    eng.forward(x0, y.cuda(), e, 8, True)
+    eng.loss_sums()
+    eng.loss_gate(11, 3.0, 0.01)
+    eng.backward()
+    s = eng.scal.cpu().numpy()
+    for k in ("loss", "loss_rec", "loss_rec_p", "loss_p", "kld"):
+        assert abs(s[L.SCAL[k]] - info[k]) <= 3e-2 * abs(info[k]), (k, s[L.SCAL[k]], info[k])
+    for k in ("fc_mu.weight", "fc_var.bias", "post_conv.weight", "decoder1.0.weight", "decoder_p3.0.weight", "emb_p.weight",
+              "layer2.0.conv2.weight", "layer1.0.conv1.weight", "conv1.weight", "bn1.weight", "layer2.0.bn2.bias"):
+        assert l2_err(eng.grad[k].cpu(), grads[k]) < 0.25, k
+    live = [k for k in grads if not (k.endswith("1.1.bias") or k.endswith("2.0.bias"))]
+    a = torch.cat([eng.grad[k].flatten().cpu().double() for k in live])
+    b = torch.cat([grads[k].flatten().double() for k in live])
+    assert float((a * b).sum() / a.norm() / b.norm()) > 0.998
+    eng.adam_step()
+    assert np.isfinite(float(eng.scal[L.SCAL["grad_norm"]]))
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_purification_bf16_close_to_fp32_and_shard_invariant(stage):
+    ocfg, e32, p = _engine(L.F32, 256)
+    _, e16, _ = _engine(L.BF16, 256)
+    N = 512
+    rng = np.random.default_rng(1)
+    data = torch.from_numpy(rng.integers(0, 256, (N, 32, 32, 3), dtype=np.uint8)).cuda()
+    labels = (torch.arange(N, device="cuda") % 10).long()
+    outs = {}
+    for name, eng in (("f32", e32), ("bf16", e16)):
+        eng.seed = 5
+        out = torch.zeros_like(data)
+        noise = torch.zeros(N, 3, 32, 32, device="cuda")
+        for lo in range(0, N, 256):
+            eng.purify_batch(data, out, noise, labels, lo, 256, stage)
+        outs[name] = (out, noise)
+    d = (outs["f32"][0].int() - outs["bf16"][0].int()).abs()
+    # the recipe's untrained decoder_p emits |p| ~ 1-4 (a trained one ~0.05), so bf16 rounding inside the decoder
+    # is worth several LSB on a few pixels here
+    assert int(d.max()) <= 16 and float((d <= 4).float().mean()) > 0.985 and float(d.float().mean()) < 0.75
+    # bit-exact invariance to batching holds in bf16 as well
+    out2 = torch.zeros_like(data)
+    noise2 = torch.zeros(N, 3, 32, 32, device="cuda")
+    for lo in range(0, N, 100):
+        e16.purify_batch(data, out2, noise2, labels, lo, min(100, N - lo), stage)
+    assert torch.equal(out2, outs["bf16"][0]) and torch.equal(noise2, outs["bf16"][1])
