@@ -252,11 +252,21 @@ int dvae_norm_bwd(const void* dy, const void* y, const void* x, void* dx, void* 
 }
 
 // ---------------------------------------------------------------------------------------------
-int dvae_emb_add_fwd(const float* emb, const int64_t* y, const void* add, void* out, int B, int HW, int C, int spatial,
+int dvae_emb_pack(const float* emb, void* table, int num_classes, int HW, int C, int spatial, int dtype, void* st) {
+    if (num_classes <= 0 || HW <= 0 || C <= 0) DVAE_FAIL(DVAE_EINVAL, "emb_pack: empty");
+    const long total = (long)num_classes * (spatial ? (long)HW * C : C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((emb_pack_kernel<T>), dim3(grid_for(total)), dim3(256), 0, S(st), emb, (T*)table,
+                                         num_classes, HW, C, spatial);)
+    DVAE_CHECK_LAUNCH("emb_pack");
+    return DVAE_OK;
+}
+
+int dvae_emb_add_fwd(const void* table, const int64_t* y, const void* add, void* out, int B, int HW, int C, int spatial,
                      int dtype, void* st) {
-    if (B <= 0 || HW <= 0 || C <= 0) DVAE_FAIL(DVAE_EINVAL, "emb_add: empty");
-    DISPATCH_T(dtype, hipLaunchKernelGGL((emb_add_kernel<T>), dim3(grid_for((long)B * HW * C)), dim3(256), 0, S(st), emb,
-                                         y, (const T*)add, (T*)out, B, HW, C, spatial);)
+    const int vec = dtype == DVAE_BF16 ? 8 : 4;
+    if (B <= 0 || HW <= 0 || C <= 0 || C % vec) DVAE_FAIL(DVAE_EINVAL, "emb_add: C must be a positive multiple of %d", vec);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((emb_add_kernel<T>), dim3(grid_for((long)B * HW * C / vec)), dim3(256), 0, S(st),
+                                         (const T*)table, y, (const T*)add, (T*)out, B, HW, C, spatial);)
     DVAE_CHECK_LAUNCH("emb_add");
     return DVAE_OK;
 }
@@ -275,8 +285,8 @@ int dvae_emb_bwd(const void* dout, const int64_t* y, float* demb, int B, int HW,
 int dvae_philox_normal(float* out, const int32_t* index, int64_t first, int B, int per_image, uint64_t seed,
                        uint32_t stream_id, void* st) {
     if (B <= 0 || per_image <= 0 || per_image % 4) DVAE_FAIL(DVAE_EINVAL, "philox: per_image must be a positive multiple of 4");
-    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, S(st), out, index,
-                       (long)first, B, per_image, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id);
+    PhiloxKey key = {index, (long)first, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id};
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, S(st), out, B, per_image, key);
     DVAE_CHECK_LAUNCH("philox_normal");
     return DVAE_OK;
 }
@@ -284,9 +294,23 @@ int dvae_philox_normal(float* out, const int32_t* index, int64_t first, int B, i
 int dvae_reparam_kl_fwd(const float* mulv, const float* eps, void* z1, float* kl_partial, int rows, int L, int dtype,
                         void* st) {
     if (rows <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");
+    if (!eps) DVAE_FAIL(DVAE_EINVAL, "reparam: eps is NULL (use dvae_reparam_kl_fwd_philox to draw in-kernel)");
+    PhiloxKey key = {nullptr, 0, 0u, 0u, 0u};
     DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), mulv, eps,
-                                         (T*)z1, kl_partial, rows, L);)
+                                         (float*)nullptr, (T*)z1, kl_partial, rows, L, rows, key);)
     DVAE_CHECK_LAUNCH("reparam_kl_fwd");
+    return DVAE_OK;
+}
+
+int dvae_reparam_kl_fwd_philox(const float* mulv, float* eps_out, void* z1, float* kl_partial, int B, int rows_per_image,
+                               int L, const int32_t* index, int64_t first, uint64_t seed, uint32_t stream_id, int dtype,
+                               void* st) {
+    if (B <= 0 || rows_per_image <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");
+    PhiloxKey key = {index, (long)first, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id};
+    DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), mulv,
+                                         (const float*)nullptr, eps_out, (T*)z1, kl_partial, B * rows_per_image, L,
+                                         rows_per_image, key);)
+    DVAE_CHECK_LAUNCH("reparam_kl_fwd_philox");
     return DVAE_OK;
 }
 

@@ -50,19 +50,44 @@ __global__ void act_to_nchw_kernel(const T* act, float* nchw, int B, int C, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// class embedding: out[b][px][c] = emb[y[b]][spatial ? c*HW + px : c] + add[b][px][c]
+// class embedding.  The reference reshapes emb[y] (width C*HW) to NCHW; the packed table holds it NHWC in
+// the activation dtype ([class][px][c], or [class][c] when not spatial) so that the per-step gather-add
+//     out[b][px][c] = table[y[b]][px][c] + add[b][px][c]
+// is a pure 16-byte-vector stream.  The table is re-packed whenever the parameters change.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void emb_add_kernel(const float* emb, const int64_t* y, const T* add, T* out, int B, int HW, int C, int spatial) {
-    const long total = (long)B * HW * C;
-    const long width = spatial ? (long)C * HW : C;
+__global__ void emb_pack_kernel(const float* emb, T* table, int num_classes, int HW, int C, int spatial) {
+    const long total = (long)num_classes * (spatial ? (long)HW * C : C);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long bp = i / C;
-        const int px = (int)(bp % HW), b = (int)(bp / HW);
-        float v = emb[(long)y[b] * width + (spatial ? (long)c * HW + px : c)];
-        if (add) v += (float)add[i];
-        out[i] = (T)v;
+        if (spatial) {
+            const int c = (int)(i % C);
+            const long kp = i / C;
+            const int px = (int)(kp % HW), k = (int)(kp / HW);
+            table[i] = (T)emb[((long)k * C + c) * HW + px];
+        } else {
+            table[i] = (T)emb[i];
+        }
+    }
+}
+
+template <typename T>
+__global__ void emb_add_kernel(const T* table, const int64_t* y, const T* add, T* out, int B, int HW, int C, int spatial) {
+    constexpr int VEC = Act<T>::VEC;
+    const int CV = C / VEC;
+    const long per = (long)HW * CV;
+    const long total = (long)B * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const long r = i % per;
+        const T* src = table + (spatial ? ((long)y[b] * per + r) * VEC : ((long)y[b] * CV + r % CV) * VEC);
+        float v[VEC], a[VEC];
+        Act<T>::load(src, v);
+        if (add) {
+            Act<T>::load(add + i * VEC, a);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] += a[k];
+        }
+        Act<T>::store(out + i * VEC, v);
     }
 }
 
@@ -104,27 +129,37 @@ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-__global__ void philox_normal_kernel(float* out, const int32_t* index, long first, int B, int per_image,
-                                     uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id) {
+struct PhiloxKey {
+    const int32_t* index;   // per-image global index, or NULL: first + b
+    long first;
+    uint32_t seed_lo, seed_hi, stream_id;
+};
+
+// four standard normals for quad q of image img
+__device__ inline f32x4 philox_normal4(const PhiloxKey& k, uint64_t img, uint32_t q) {
+    uint32_t r[4];
+    philox4x32_10(q, (uint32_t)img, (uint32_t)(img >> 32), k.stream_id, k.seed_lo, k.seed_hi, r);
+    float n[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+        const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        n[2 * h] = rad * cs; n[2 * h + 1] = rad * sn;
+    }
+    f32x4 v = {n[0], n[1], n[2], n[3]};
+    return v;
+}
+
+__global__ void philox_normal_kernel(float* out, int B, int per_image, const PhiloxKey key) {
     const int quads = per_image / 4;
     const long total = (long)B * quads;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / quads), q = (int)(i % quads);
-        const uint64_t img = index ? (uint64_t)index[b] : (uint64_t)(first + b);
-        uint32_t r[4];
-        philox4x32_10((uint32_t)q, (uint32_t)img, (uint32_t)(img >> 32), stream_id, seed_lo, seed_hi, r);
-        float n[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
-            const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
-            const float rad = sqrtf(-2.0f * logf(u1));
-            float sn, cs;
-            sincosf(6.283185307179586f * u2, &sn, &cs);
-            n[2 * h] = rad * cs; n[2 * h + 1] = rad * sn;
-        }
-        f32x4 v = {n[0], n[1], n[2], n[3]};
-        *reinterpret_cast<f32x4*>(out + ((long)b * per_image + (long)q * 4)) = v;
+        const uint64_t img = key.index ? (uint64_t)key.index[b] : (uint64_t)(key.first + b);
+        *reinterpret_cast<f32x4*>(out + ((long)b * per_image + (long)q * 4)) = philox_normal4(key, img, (uint32_t)q);
     }
 }
 
@@ -132,9 +167,12 @@ __global__ void philox_normal_kernel(float* out, const int32_t* index, long firs
 // reparameterise + KL.  mulv fp32 [rows][2L]; one wave walks rows, 4 channels per lane per step.
 // z1 = eps * exp(0.5*lv) + mu ;  KL row term = -0.5 * sum_c (1 + lv - mu^2 - exp(lv))
 // ------------------------------------------------------------------------------------------------
+// eps == NULL: the noise is drawn in-kernel (same Philox stream as philox_normal_kernel for an
+// [image][row][channel] tensor) and, when eps_out != NULL, stored for the backward pass.
 template <typename T>
-__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, const float* eps, T* z1,
-                                                             float* kl_partial, int rows, int L) {
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, const float* eps, float* eps_out, T* z1,
+                                                             float* kl_partial, int rows, int L, int rows_per_image,
+                                                             const PhiloxKey key) {
     __shared__ float red[4];
     const int LV = L / 4;
     const long total = (long)rows * LV;
@@ -144,7 +182,16 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, 
         const int c = (int)(i % LV) * 4;
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mulv + row * 2 * L + c);
         const f32x4 lv = *reinterpret_cast<const f32x4*>(mulv + row * 2 * L + L + c);
-        const f32x4 e = *reinterpret_cast<const f32x4*>(eps + row * L + c);
+        f32x4 e;
+        if (eps) {
+            e = *reinterpret_cast<const f32x4*>(eps + row * L + c);
+        } else {
+            const int b = (int)(row / rows_per_image);
+            const long in_img = (row % rows_per_image) * L + c;
+            const uint64_t img = key.index ? (uint64_t)key.index[b] : (uint64_t)(key.first + b);
+            e = philox_normal4(key, img, (uint32_t)(in_img >> 2));
+            if (eps_out) *reinterpret_cast<f32x4*>(eps_out + row * L + c) = e;
+        }
         float z[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

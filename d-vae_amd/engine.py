@@ -140,6 +140,16 @@ def _numel(shape):
     return n
 
 
+@dataclass
+class PhiloxEps:
+    """Reparameterisation noise to be drawn inside the reparameterise kernel: Philox4x32-10 keyed by
+    (engine seed, stream_id) and counted by (global image index, element), so the draw for an image does
+    not depend on batch composition, shard or world size."""
+    first: int = 0
+    index: torch.Tensor | None = None     # int32 [b] global image indices, or None: first + i
+    stream_id: int = 0
+
+
 class DVAEEngine:
     def __init__(self, cfg: DVAEConfig, max_batch: int, device="cuda", dtype: int = F32, seed: int = 0):
         if cfg.spatial_emb and cfg.image_size != 32:
@@ -199,6 +209,7 @@ class DVAEEngine:
                     continue
                 n = self.lib.dvae_conv_packed_elems(C.byref(d), op)
                 self.packed[(name, op)] = torch.zeros(n, device=self.dev, dtype=self.tdt)
+        self.emb_table = torch.zeros(self.param["emb_p.weight"].numel(), device=self.dev, dtype=self.tdt)
         # ---- scalars / partials ----------------------------------------------------------------
         self.hyper = torch.zeros(8, **f32)
         self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if self.dev.type == "cuda" else torch.zeros(8)
@@ -291,6 +302,8 @@ class DVAEEngine:
         for (name, op), t in self.packed.items():
             check(self.lib.dvae_conv_pack(ptr(self.param[name + ".weight"]), ptr(t), C.byref(self.desc(name, 1)), op,
                                           self.dtype, st))
+        check(self.lib.dvae_emb_pack(ptr(self.param["emb_p.weight"]), ptr(self.emb_table), self.cfg.num_classes, self.h * self.h,
+                                     128, int(self.cfg.spatial_emb), self.dtype, st))
         self.packed_valid = True
 
     def fold_bn(self):
@@ -375,6 +388,11 @@ class DVAEEngine:
         return e
 
     def eps_philox(self, b, first=0, index=None, stream_id=0):
+        """Noise specification for forward(): drawn in-kernel (no eps tensor round trip through HBM)."""
+        return PhiloxEps(int(first), index, int(stream_id))
+
+    def eps_philox_tensor(self, b, first=0, index=None, stream_id=0):
+        """The same noise materialised as an fp32 act tensor (tests, debugging)."""
         e = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32)
         check(self.lib.dvae_philox_normal(ptr(e), ptr(index), int(first), b, self.h * self.h * self.Ld, self.seed,
                                           int(stream_id), L.stream()))
@@ -394,7 +412,9 @@ class DVAEEngine:
         """x0: input act [B,S,S,4]; y: int64 [b]; eps: fp32 act [B,h,h,L].  Leaves rec_pre / p (and
         every intermediate needed by backward) in the engine's buffers and returns them."""
         stem_out = self.stem(x0, b, train)
-        _, _, z = self.latent(stem_out, eps, b)
+        _, _, z = self.latent(stem_out, eps, b, keep_eps=train)
+        if isinstance(eps, PhiloxEps):
+            eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
         rec_pre = self._decoder("decoder", z, b)
         p = self.perturb(stem_out, z, y, b)
         self._last = dict(b=b, x0=x0, y=y, eps=eps, stem_out=stem_out, train=train)
@@ -452,7 +472,7 @@ class DVAEEngine:
             a = out
         return a
 
-    def latent(self, stem_out, eps, b):
+    def latent(self, stem_out, eps, b, keep_eps=True):
         """encode (fc_mu|fc_var as one GEMM) -> reparameterise (+ KL partial sums) -> post_conv.
         resnet.py:2197-2199, :2245-2246, :2257-2259."""
         if not self.packed_valid:
@@ -461,8 +481,13 @@ class DVAEEngine:
         mulv = self.act("mulv", h, 2 * self.Ld, f32=True)
         self._conv("fc", stem_out, mulv, b, shift=self.param["fc.bias"], out_f32=True)
         z1 = self.act("z1", h, self.Ld)
-        check(self.lib.dvae_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z1), ptr(self.kl_partial), b * h * h, self.Ld,
-                                           self.dtype, L.stream()))
+        if isinstance(eps, PhiloxEps):
+            eps_out = self.buf("eps", (self.B, h, h, self.Ld), torch.float32) if keep_eps else None
+            check(self.lib.dvae_reparam_kl_fwd_philox(ptr(mulv), ptr(eps_out), ptr(z1), ptr(self.kl_partial), b, h * h, self.Ld,
+                                                      ptr(eps.index), eps.first, self.seed, eps.stream_id, self.dtype, L.stream()))
+        else:
+            check(self.lib.dvae_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z1), ptr(self.kl_partial), b * h * h, self.Ld,
+                                               self.dtype, L.stream()))
         z = self.act("z", h, 128)
         self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"])
         return mulv, z1, z
@@ -474,7 +499,7 @@ class DVAEEngine:
         add = None
         if cfg.sample_wise:
             add = stem_out if cfg.use_y else z
-        check(self.lib.dvae_emb_add_fwd(ptr(self.param["emb_p.weight"]), ptr(y), ptr(add), ptr(ep), b, h * h, 128,
+        check(self.lib.dvae_emb_add_fwd(ptr(self.emb_table), ptr(y), ptr(add), ptr(ep), b, h * h, 128,
                                         int(cfg.spatial_emb), self.dtype, L.stream()))
         return self._decoder("decoder_p", ep, b)
 

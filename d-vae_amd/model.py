@@ -275,7 +275,7 @@ class ResNetDVAE(nn.Module):
         L.check(eng.lib.dvae_nchw_to_act(L.ptr(stem_out.contiguous().float()), L.ptr(a), b, 128, h, h, eng.dtype, L.stream()))
         e = eng.eps_from_nchw(eps) if eps is not None else eng.eps_philox(b, first=self._draws * b, stream_id=7)
         self._draws += 1
-        mulv, _, z = eng.latent(a, e, b)
+        mulv, _, z = eng.latent(a, e, b, keep_eps=False)
         rec_pre = eng._decoder("decoder", z, b)
         rec = torch.sigmoid(eng.to_nchw(rec_pre, b, 3, eng.S))
         return rec, eng.to_nchw(mulv, b, eng.Ld, h, 0), eng.to_nchw(mulv, b, eng.Ld, h, eng.Ld), eng.to_nchw(z, b, 128, h)

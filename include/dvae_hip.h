@@ -113,7 +113,9 @@ int dvae_norm_bwd(const void* dy, const void* y, const void* x,
                   int groups, int rows_per_group, int C, int relu, int dtype, void* stream);
 
 /* ---- class embedding of decoder_p's input (resnet.py:2211-2221) ------------------------------ */
-int dvae_emb_add_fwd(const float* emb, const int64_t* y, const void* add /* or NULL */, void* out,
+/* emb [num_classes][C*HW] (reference layout, NCHW per class) -> table [class][px][c] in the act dtype */
+int dvae_emb_pack(const float* emb, void* table, int num_classes, int HW, int C, int spatial, int dtype, void* stream);
+int dvae_emb_add_fwd(const void* table, const int64_t* y, const void* add /* or NULL */, void* out,
                      int B, int HW, int C, int spatial, int dtype, void* stream);
 int dvae_emb_bwd(const void* dout, const int64_t* y, float* demb, int B, int HW, int C,
                  int num_classes, int spatial, int dtype, void* stream);
@@ -125,6 +127,11 @@ int dvae_philox_normal(float* out, const int32_t* image_index /* [B] or NULL */,
                        int B, int per_image, uint64_t seed, uint32_t stream_id, void* stream);
 int dvae_reparam_kl_fwd(const float* mulv, const float* eps, void* z1, float* kl_partial /* [DVAE_NPARTIAL] */,
                         int rows, int L, int dtype, void* stream);
+/* same, with eps drawn in-kernel from the Philox stream of dvae_philox_normal for an [image][rows][L]
+ * tensor; eps_out (or NULL) receives it for the backward pass. */
+int dvae_reparam_kl_fwd_philox(const float* mulv, float* eps_out, void* z1, float* kl_partial, int B, int rows_per_image,
+                               int L, const int32_t* image_index /* [B] or NULL */, int64_t first_image, uint64_t seed,
+                               uint32_t stream_id, int dtype, void* stream);
 int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal,
                         void* dmulv, int rows, int L, int dtype, void* stream);
 

@@ -212,3 +212,22 @@ def test_purification_vs_golden(golden_dir, stage):
     diff = np.abs(out.cpu().numpy().astype(np.int32) - g[f"stage{stage}.u8"].astype(np.int32))
     # truncation flips by one LSB wherever the fp32 value differs by an ulp across k/255
     assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
+
+
+def test_in_kernel_philox_equals_materialised_noise():
+    """forward() with a PhiloxEps draws exactly the numbers dvae_philox_normal writes for the same key."""
+    ocfg, eng, p = make_engine({}, 4)
+    x, y, _ = O.make_inputs(ocfg, 4)
+    eng.seed = 77
+    idx = torch.tensor([5, 100000, 7, 3], dtype=torch.int32, device="cuda")
+    x0 = eng.input_from_nchw(x.cuda())
+    for train in (True, False):
+        rec_pre, pp = eng.forward(x0, y.cuda(), eng.eps_philox(4, index=idx, stream_id=3), 4, train)
+        a = (rec_pre.clone(), pp.clone(), eng.act("z1", 16, 256).clone())
+        e = eng.eps_philox_tensor(4, index=idx, stream_id=3).clone()
+        if train:
+            assert torch.equal(eng._last["eps"][:4], e[:4])
+            eng.load_params(p)          # restore the BatchNorm running statistics the train pass advanced
+            continue
+        rec_pre, pp = eng.forward(x0, y.cuda(), e, 4, train)
+        assert torch.equal(a[0], rec_pre) and torch.equal(a[1], pp) and torch.equal(a[2], eng.act("z1", 16, 256))
