@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include "elementwise.hpp"
 #include "igemm.hpp"
+#include "conv_halo.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -96,6 +97,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     if (ep) e = *ep;
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
+    if (try_launch_halo_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_halo");
+        return DVAE_OK;
+    }
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
 }
 
@@ -107,6 +112,10 @@ int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, co
     if (rc) return rc;
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 1, S(st));
+    if (try_launch_halo_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_halo");
+        return DVAE_OK;
+    }
     return launch_igemm<bf16>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st));
 }
 

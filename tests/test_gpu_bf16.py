@@ -35,6 +35,9 @@ CONVS = [
     (64, 32, 3, 1, 1, True, 32, True),
     (32, 3, 3, 1, 1, True, 32, True),
     (64, 128, 3, 2, 1, False, 13, False),
+    (64, 64, 3, 1, 1, False, 16, False),      # LDS-halo kernel with 16-wide tiles
+    (32, 64, 3, 1, 1, False, 64, False),      # 64x64 images: two tiles per row
+    (64, 64, 3, 1, 1, True, 32, True),
 ]
 
 
@@ -160,3 +163,35 @@ def test_purification_bf16_close_to_fp32_and_shard_invariant(stage):
     for lo in range(0, N, 100):
         e16.purify_batch(data, out2, noise2, labels, lo, min(100, N - lo), stage)
     assert torch.equal(out2, outs["bf16"][0]) and torch.equal(noise2, outs["bf16"][1])
+
+
+def test_conv_bf16_fused_epilogue_and_accumulate():
+    """scale/shift + residual + ReLU epilogue and the accumulate mode on the LDS-halo kernel."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    q = lambda t: t.bfloat16().float()      # noqa: E731
+    B, cin, cout, hin = 3, 64, 64, 32
+    w = q(torch.randn(cout, cin, 3, 3, generator=g) / 24)
+    x = q(torch.randn(B, cin, hin, hin, generator=g))
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = q(torch.randn(B, cout, hin, hin, generator=g))
+    conv = F.conv2d(x, w, None, 1, 1)
+    ref = F.relu(q(conv * sc[None, :, None, None] + sh[None, :, None, None]) + res)
+    d = L.ConvDesc(B, hin, hin, cin, cout, 3, 3, 1, 1, 0)
+    st = L.stream()
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), 0), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().data_ptr(), pk.data_ptr(), C.byref(d), 0, L.BF16, st))
+    ya = torch.empty(B, hin, hin, cout, device="cuda", dtype=torch.bfloat16)
+    scd, shd, resa = sc.cuda(), sh.cuda(), to_act(res, L.BF16)
+    ep = L.Epilogue(scd.data_ptr(), shd.data_ptr(), resa.data_ptr(), 1, 0)
+    L.check(lib.dvae_conv_fwd(to_act(x, L.BF16).data_ptr(), pk.data_ptr(), C.byref(ep), ya.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(ya, cout), ref) < 6e-3
+    # dgrad with accumulate: dx <- dx + W^T dy
+    pkd = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), 1), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().data_ptr(), pkd.data_ptr(), C.byref(d), 1, L.BF16, st))
+    gy = q(torch.randn(B, cout, hin, hin, generator=g))
+    base = q(torch.randn(B, cin, hin, hin, generator=g))
+    dxa = to_act(base, L.BF16)
+    L.check(lib.dvae_conv_dgrad(to_act(gy, L.BF16).data_ptr(), pkd.data_ptr(), dxa.data_ptr(), 1, C.byref(d), L.BF16, st))
+    want = base + q(F.conv_transpose2d(gy, w, None, 1, 1))
+    assert rel_err(from_act(dxa, cin), want) < 6e-3
