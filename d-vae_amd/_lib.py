@@ -36,6 +36,9 @@ _SIGS = {
     "dvae_act_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dvae_conv_packed_elems": (_Z, [C.POINTER(ConvDesc), _I]),
     "dvae_conv_pack": (C.c_int, [_P, _P, C.POINTER(ConvDesc), _I, _I, _P]),
+    "dvae_conv_pack_job_bytes": (_Z, []),
+    "dvae_conv_pack_job": (C.c_int, [_P, _P, C.POINTER(ConvDesc), _I, _I, _P]),
+    "dvae_conv_pack_batch": (C.c_int, [_P, _I, _I, _P]),
     "dvae_conv_fwd": (C.c_int, [_P, _P, C.POINTER(Epilogue), _P, C.POINTER(ConvDesc), _I, _P]),
     "dvae_conv_dgrad": (C.c_int, [_P, _P, _P, _I, C.POINTER(ConvDesc), _I, _P]),
     "dvae_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),

@@ -74,15 +74,25 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs a) {
     };
 
     load_w(0);
-    // ---- input halo -> LDS -------------------------------------------------------------------
-    for (int v = tid; v < HP * VPP; v += 256) {
-        const int hp = v / VPP, cv = v % VPP;
-        const int hy = hp / HWD, hx = hp % HWD;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    // ---- input halo -> LDS: every global load is issued before the first LDS store ---------------
+    constexpr int HV = (HP * VPP + 255) / 256;
+    u32x4 hreg[HV];
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        const int v = tid + 256 * k;
         u32x4 val = {0u, 0u, 0u, 0u};
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-            val = *reinterpret_cast<const u32x4*>(in + ((long)(b * a.H + iy) * a.W + ix) * CIN + cv * 8);
-        *reinterpret_cast<u32x4*>(halo + hp * RS + cv * 16) = val;
+        if (v < HP * VPP) {
+            const int hp = v / VPP, cv = v % VPP;
+            const int iy = y0 - 1 + hp / HWD, ix = x0 - 1 + hp % HWD;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                val = *reinterpret_cast<const u32x4*>(in + ((long)(b * a.H + iy) * a.W + ix) * CIN + cv * 8);
+        }
+        hreg[k] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        const int v = tid + 256 * k;
+        if (v < HP * VPP) *reinterpret_cast<u32x4*>(halo + (v / VPP) * RS + (v % VPP) * 16) = hreg[k];
     }
     store_w(0);
     __syncthreads();

@@ -87,6 +87,30 @@ int dvae_conv_pack(const float* w, void* out, const dvae_conv_desc* d, int op, i
     return DVAE_OK;
 }
 
+size_t dvae_conv_pack_job_bytes(void) { return sizeof(PackArgs); }
+
+int dvae_conv_pack_job(const float* w, void* out, const dvae_conv_desc* d, int op, int dtype, void* job_host) {
+    GemmPlan P;
+    if (!d || !job_host) DVAE_FAIL(DVAE_EINVAL, "null desc / job");
+    int rc = build_plan(*d, op, dtype, P);
+    if (rc) return rc;
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = w; a.out = out; a.N = P.N; a.Npad = P.Npad; a.Cg = P.Cg; a.cg_log2 = P.cg_log2; a.Ktot = P.Ktot;
+    a.sN = P.sN; a.sC = P.sC; a.nphase = P.nphase;
+    for (int i = 0; i < 4; ++i) a.pk[i] = P.pk[i];
+    memcpy(job_host, &a, sizeof(a));
+    return DVAE_OK;
+}
+
+int dvae_conv_pack_batch(const void* jobs_dev, int njobs, int dtype, void* st) {
+    if (!jobs_dev || njobs <= 0) DVAE_FAIL(DVAE_EINVAL, "pack_batch: no jobs");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pack_weight_batch_kernel<T>), dim3(48, njobs), dim3(256), 0, S(st),
+                                         (const PackArgs*)jobs_dev);)
+    DVAE_CHECK_LAUNCH("conv_pack_batch");
+    return DVAE_OK;
+}
+
 int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* y, const dvae_conv_desc* d, int dtype,
                   void* st) {
     GemmPlan P;
@@ -153,7 +177,7 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     r.cx_log2 = W.cx_log2; r.Cd = W.Cd; r.ntaps = W.ntaps; r.sX = W.sX; r.sD = W.sD;
     memcpy(r.woff, W.woff, sizeof(r.woff));
     const long tot = (long)W.Kpad * W.CdPad;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, S(st), r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, S(st), r);
     DVAE_CHECK_LAUNCH("wgrad_reduce");
     if (db) {
         float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
@@ -167,7 +191,7 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
             hipLaunchKernelGGL((colsum_partial_kernel<bf16>), dim3(COLSUM_BLOCKS), dim3(256), 0, S(st), (const bf16*)src,
                                part, rows, CS);
         DVAE_CHECK_LAUNCH("colsum_partial");
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->Cout + 63) / 64), dim3(64), 0, S(st), part, db, COLSUM_BLOCKS,
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->Cout + 63) / 64), dim3(256), 0, S(st), part, db, COLSUM_BLOCKS,
                            CS, d->Cout);
         DVAE_CHECK_LAUNCH("colsum_reduce");
     }
@@ -203,7 +227,7 @@ int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* ga
                hipLaunchKernelGGL((norm_stats_kernel<T>), dim3(g.nchunk, groups), dim3(256), 0, S(st), (const T*)x,
                                   partial, rows_per_group, C, g.rows_per_chunk, g.nchunk);
                DVAE_CHECK_LAUNCH("norm_stats");
-               hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 31) / 32, groups), dim3(256), 0, S(st), partial,
+               hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), partial,
                                   g.nchunk, C, gamma, beta, running_mean, running_var, save_mean, save_invstd,
                                   scale_shift, momentum, eps);
                DVAE_CHECK_LAUNCH("norm_finalize");
@@ -250,7 +274,7 @@ int dvae_norm_bwd(const void* dy, const void* y, const void* x, void* dx, void* 
                                   (const T*)dy, (const T*)y, (const T*)x, save_mean, save_invstd, partial,
                                   rows_per_group, C, g.rows_per_chunk, g.nchunk, relu);
                DVAE_CHECK_LAUNCH("norm_bwd_reduce");
-               hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 31) / 32, groups), dim3(256), 0, S(st), partial,
+               hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), partial,
                                   g.nchunk, C, rows_per_group, gamma, save_invstd, coef, dgamma, dbeta);
                DVAE_CHECK_LAUNCH("norm_bwd_finalize");
                hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, S(st),

@@ -165,6 +165,29 @@ __global__ void pack_weight_kernel(const PackArgs a) {
     }
 }
 
+// All conv weights of a model in one launch: blockIdx.y selects a job (a PackArgs record in device
+// memory), blockIdx.x grid-strides over that job's elements.
+template <typename T>
+__global__ void pack_weight_batch_kernel(const PackArgs* jobs) {
+    const PackArgs& a = jobs[blockIdx.y];
+    const long total = (long)a.Npad * a.Ktot;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / a.Ktot), k = (int)(e % a.Ktot);
+        float v = 0.f;
+        if (n < a.N) {
+            for (int i = 0; i < a.nphase; ++i) {
+                const PackPhase& pk = a.pk[i];
+                if (k >= pk.koff && k < pk.koff + pk.kcols) {
+                    const int kk = k - pk.koff;
+                    const int tap = kk >> a.cg_log2, c = kk & ((1 << a.cg_log2) - 1);
+                    if (tap < pk.ntaps && c < a.Cg) v = a.w[(long)n * a.sN + (long)c * a.sC + pk.woff[tap]];
+                }
+            }
+        }
+        reinterpret_cast<T*>(a.out)[e] = (T)v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gather GEMM
 // ------------------------------------------------------------------------------------------------
@@ -595,16 +618,26 @@ struct WreduceArgs {
     int woff[16];
 };
 
-__global__ void wgrad_reduce_kernel(const WreduceArgs a) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
+    // 64 consecutive slab elements per block; 4 lanes split the S slabs (interleaved), each with
+    // independent loads in flight; the 4 partial sums are combined in lane order (deterministic).
+    __shared__ float part[4][64];
     const long total = (long)a.Kpad * a.CdPad;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int i = sl;
+        for (; i + 4 < a.S; i += 8) { s0 += a.ws[(long)i * total + e]; s1 += a.ws[(long)(i + 4) * total + e]; }
+        if (i < a.S) s0 += a.ws[(long)i * total + e];
+    }
+    part[sl][el] = s0 + s1;
+    __syncthreads();
+    if (sl != 0 || e >= total) return;
     const int k = (int)(e / a.CdPad), cd = (int)(e % a.CdPad);
     const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
     if (tap >= a.ntaps || c >= a.Cx || cd >= a.Cd) return;
-    float s = 0.f;
-    for (int i = 0; i < a.S; ++i) s += a.ws[(long)i * total + e];
-    a.dw[(long)cd * a.sD + (long)c * a.sX + a.woff[tap]] = s;
+    a.dw[(long)cd * a.sD + (long)c * a.sX + a.woff[tap]] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
 }
 
 // column sums of an [rows][CS] activation tensor (bias gradients), two deterministic stages
@@ -636,12 +669,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, float* 
     }
 }
 
-__global__ void colsum_reduce_kernel(const float* partial, float* out, int nblk, int CS, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int i = 0; i < nblk; ++i) s += partial[(long)i * CS + c];
-    out[c] = s;
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* partial, float* out, int nblk, int CS, int C) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int i = sl;
+        for (; i + 4 < nblk; i += 8) { s0 += partial[(long)i * CS + c]; s1 += partial[(long)(i + 4) * CS + c]; }
+        if (i < nblk) s0 += partial[(long)i * CS + c];
+    }
+    part[sl][cl] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && c < C) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 }  // namespace dvae

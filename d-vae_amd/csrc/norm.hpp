@@ -107,8 +107,9 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* x, float* part
     }
 }
 
-// One workgroup per (32-channel tile, group): 8 lanes per channel merge the chunk triples, then
-// mean / invstd / scale / shift are written and (BatchNorm) the running statistics are updated.
+// One workgroup per (8-channel tile, group): 32 lanes per channel merge the chunk triples (interleaved),
+// a 5-level tree combines them, then mean / invstd / scale / shift are written and (BatchNorm) the
+// running statistics are updated.
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial, int nchunk, int C,
                                                             const float* gamma, const float* beta,
                                                             float* running_mean, float* running_var,
@@ -116,27 +117,27 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial
                                                             float* scale_shift, float momentum, float eps) {
     __shared__ float sn[256], sm[256], sq[256];
     const int g = blockIdx.y;
-    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int cl = threadIdx.x & 7, lane32 = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     float n = 0.f, m = 0.f, q = 0.f;
     if (c < C) {
-        for (int ch = lane8; ch < nchunk; ch += 8) {
+        for (int ch = lane32; ch < nchunk; ch += 32) {
             const float* p = partial + ((long)(g * nchunk + ch) * 3) * C + c;
             chan_merge(n, m, q, p[0], p[C], p[2 * C]);
         }
     }
     sn[threadIdx.x] = n; sm[threadIdx.x] = m; sq[threadIdx.x] = q;
     __syncthreads();
-    for (int step = 4; step > 0; step >>= 1) {
-        if (lane8 < step) {
-            const int o = threadIdx.x + step * 32;
+    for (int step = 16; step > 0; step >>= 1) {
+        if (lane32 < step) {
+            const int o = threadIdx.x + step * 8;
             float a_n = sn[threadIdx.x], a_m = sm[threadIdx.x], a_q = sq[threadIdx.x];
             chan_merge(a_n, a_m, a_q, sn[o], sm[o], sq[o]);
             sn[threadIdx.x] = a_n; sm[threadIdx.x] = a_m; sq[threadIdx.x] = a_q;
         }
         __syncthreads();
     }
-    if (lane8 == 0 && c < C) {
+    if (lane32 == 0 && c < C) {
         const float cnt = sn[threadIdx.x], mean = sm[threadIdx.x];
         const float var = sq[threadIdx.x] / cnt;
         const float invstd = 1.0f / sqrtf(var + eps);
@@ -252,22 +253,22 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* par
                                                                 float* dgamma, float* dbeta) {
     __shared__ float a1[256], a2[256];
     const int g = blockIdx.y;
-    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int cl = threadIdx.x & 7, lane32 = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
-        for (int ch = lane8; ch < nchunk; ch += 8) {
+        for (int ch = lane32; ch < nchunk; ch += 32) {
             const float* p = partial + ((long)(g * nchunk + ch) * 2) * C + c;
             s1 += p[0]; s2 += p[C];
         }
     }
     a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
     __syncthreads();
-    for (int step = 4; step > 0; step >>= 1) {
-        if (lane8 < step) { a1[threadIdx.x] += a1[threadIdx.x + step * 32]; a2[threadIdx.x] += a2[threadIdx.x + step * 32]; }
+    for (int step = 16; step > 0; step >>= 1) {
+        if (lane32 < step) { a1[threadIdx.x] += a1[threadIdx.x + step * 8]; a2[threadIdx.x] += a2[threadIdx.x + step * 8]; }
         __syncthreads();
     }
-    if (lane8 == 0 && c < C) {
+    if (lane32 == 0 && c < C) {
         const float n = (float)rows_per_group;
         const float ga = gamma ? gamma[c] : 1.f;
         coef[((long)g * 3) * C + c] = ga * save_invstd[(long)g * C + c];

@@ -297,11 +297,20 @@ class DVAEEngine:
         self.packed_valid = False
         self.fold_valid = False
 
+    def _build_pack_jobs(self):
+        nb = self.lib.dvae_conv_pack_job_bytes()
+        host = torch.zeros(len(self.packed) * nb, dtype=torch.uint8)
+        for i, ((name, op), t) in enumerate(self.packed.items()):
+            check(self.lib.dvae_conv_pack_job(ptr(self.param[name + ".weight"]), ptr(t), C.byref(self.desc(name, 1)), op,
+                                              self.dtype, host.data_ptr() + i * nb))
+        self._pack_jobs = host.to(self.dev)
+
     def pack_weights(self):
+        """Refresh every packed GEMM operand image (one launch) and the NHWC embedding table."""
         st = L.stream()
-        for (name, op), t in self.packed.items():
-            check(self.lib.dvae_conv_pack(ptr(self.param[name + ".weight"]), ptr(t), C.byref(self.desc(name, 1)), op,
-                                          self.dtype, st))
+        if getattr(self, "_pack_jobs", None) is None:
+            self._build_pack_jobs()
+        check(self.lib.dvae_conv_pack_batch(ptr(self._pack_jobs), len(self.packed), self.dtype, st))
         check(self.lib.dvae_emb_pack(ptr(self.param["emb_p.weight"]), ptr(self.emb_table), self.cfg.num_classes, self.h * self.h,
                                      128, int(self.cfg.spatial_emb), self.dtype, st))
         self.packed_valid = True

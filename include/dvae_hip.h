@@ -77,6 +77,12 @@ int dvae_act_to_nchw(const void* act, float* nchw, int B, int C, int H, int W, i
  * resnet.py:27-29, :2140, :2245-2246, :2199, :2012-2023, :2034-2045. */
 size_t dvae_conv_packed_elems(const dvae_conv_desc* d, int op);
 int dvae_conv_pack(const float* w_ref, void* w_packed, const dvae_conv_desc* d, int op, int dtype, void* stream);
+/* Batched form: dvae_conv_pack_job fills one job record (dvae_conv_pack_job_bytes() bytes of host memory)
+ * per (weight, direction); the records, copied to device memory back to back, are all executed by one
+ * dvae_conv_pack_batch launch (re-packing every conv of the model after an optimiser step). */
+size_t dvae_conv_pack_job_bytes(void);
+int dvae_conv_pack_job(const float* w_ref, void* w_packed, const dvae_conv_desc* d, int op, int dtype, void* job_host);
+int dvae_conv_pack_batch(const void* jobs_dev, int njobs, int dtype, void* stream);
 int dvae_conv_fwd(const void* x, const void* w_packed_fwd, const dvae_epilogue* ep, void* y,
                   const dvae_conv_desc* d, int dtype, void* stream);
 int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int accumulate,
