@@ -6,11 +6,13 @@
 // LDS once (zero-filled outside the image), and forms the A fragment of every tap by re-addressing
 // that tile: lane r of a 32-pixel MFMA row block reads halo pixel (py+dy, px+dx) -- consecutive
 // lanes hit consecutive 144-byte (64 ch) / 80-byte (32 ch) pixel rows, conflict-free for
-// ds_read_b128.  Only the per-tap weight slab ([NT][CIN], 4-8 KB, L2-resident) streams through a
-// double-buffered LDS ring, one barrier per tap.  The output tile is staged in LDS (overlaying the
-// halo) so that global stores, the residual read and the accumulate read are 16-byte vectors over
-// whole pixel rows.  Serves every single-phase radius-1 unit-stride plan: Conv2d 3x3 s1 forward and
-// input-gradient, ConvTranspose2d 3x3 s1 forward and input-gradient (the plan supplies the taps).
+// ds_read_b128.  Workgroups are persistent (one per CU, 8 waves): the weights of every tap stay in LDS for the
+// workgroup's lifetime, tiles are strided over the grid, and the next tile's halo is fetched into
+// registers while the current tile's MFMAs run, so a tile costs two barriers and no weight traffic.
+// The MFMA is issued as D[channel][pixel] = W * X^T: each lane then owns one pixel and register
+// quads of 4 consecutive channels, so the epilogue (scale/shift, residual, ReLU, accumulate) reads and
+// writes 8-byte (bf16) / 16-byte (fp32) channel runs straight from registers, no LDS staging.
+// Serves every single-phase radius-1 unit-stride plan: Conv2d 3x3 s1 forward and input-gradient, ConvTranspose2d 3x3 s1 forward and input-gradient (the plan supplies the taps).
 #pragma once
 #include "igemm.hpp"
 
@@ -30,183 +32,162 @@ struct HaloArgs {
 };
 
 template <int CIN, int NT, int TW>
-__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     constexpr int TH = 256 / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
     constexpr int RS = CIN * 2 + 16;          // bytes per staged pixel / weight row (16-byte pad spreads banks)
     constexpr int VPP = CIN * 2 / 16;         // 16-byte vectors per pixel
-    constexpr int HALO_BYTES = HP * RS, STAGE_BYTES = 256 * NT * 2;
-    constexpr int A_BYTES = HALO_BYTES > STAGE_BYTES ? HALO_BYTES : STAGE_BYTES;
-    constexpr int WB = NT * RS;               // one weight slab
-    constexpr int WV = (NT * VPP + 255) / 256;
-    constexpr int TM = 2, TN = NT / 32, KS = CIN / 16;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + 2 * WB];
-    unsigned char* halo = smem;
-    unsigned char* wbuf = smem + A_BYTES;
+    constexpr int HALO_BYTES = HP * RS;
+    constexpr int WTAP = NT * RS;             // one tap's weight slab
+    constexpr int TN = NT / 32, KS = CIN / 16;
+    constexpr int HV = (HP * VPP + 511) / 512;
+    // persistent workgroup: all taps' weights stay in LDS, one halo tile at a time, next tile's halo in registers
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wlds = smem;                                  // [ntaps][NT][RS]
+    unsigned char* halo = smem + 9 * WTAP;                       // [HP][RS]
+    float* ssl = reinterpret_cast<float*>(smem + 9 * WTAP + HALO_BYTES);   // scale[NT], shift[NT]
 
     const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
-    const int tx = bid % a.tiles_x, ty = (bid / a.tiles_x) % a.tiles_y, b = bid / (a.tiles_x * a.tiles_y);
-    const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = blockIdx.y * NT;
     const bf16* in = reinterpret_cast<const bf16*>(a.in);
     const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = tiles_per_img * a.B;
 
-    u32x4 wreg[WV];
-    auto load_w = [&](int t) {
-#pragma unroll
-        for (int k = 0; k < WV; ++k) {
-            const int v = tid + 256 * k;
-            if (NT * VPP % 256 == 0 || v < NT * VPP) {
-                const int n = v / VPP, cv = v % VPP;
-                wreg[k] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + cv * 8);
-            }
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < WV; ++k) {
-            const int v = tid + 256 * k;
-            if (NT * VPP % 256 == 0 || v < NT * VPP) {
-                const int n = v / VPP, cv = v % VPP;
-                *reinterpret_cast<u32x4*>(wbuf + buf * WB + n * RS + cv * 16) = wreg[k];
-            }
-        }
-    };
+    // ---- weights (every tap) and the epilogue's per-channel scale/shift -> LDS, once -----------------
+    for (int v = tid; v < a.ntaps * NT * VPP; v += 512) {
+        const int t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, cv = rem % VPP;
+        *reinterpret_cast<u32x4*>(wlds + t * WTAP + n * RS + cv * 16) =
+            *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + cv * 8);
+    }
+    if (tid < NT) {
+        const int n = n0 + tid;
+        const bool live = n < a.N;
+        ssl[tid] = (live && a.scale) ? a.scale[n] : (live ? 1.f : 0.f);
+        ssl[NT + tid] = (live && a.shift) ? a.shift[n] : 0.f;
+    }
 
-    load_w(0);
-    // ---- input halo -> LDS: every global load is issued before the first LDS store ---------------
-    constexpr int HV = (HP * VPP + 255) / 256;
     u32x4 hreg[HV];
+    auto load_halo = [&](int tile) {
+        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / tiles_per_img;
+        const int y0 = ty * TH, x0 = tx * TW;
 #pragma unroll
-    for (int k = 0; k < HV; ++k) {
-        const int v = tid + 256 * k;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (v < HP * VPP) {
-            const int hp = v / VPP, cv = v % VPP;
-            const int iy = y0 - 1 + hp / HWD, ix = x0 - 1 + hp % HWD;
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                val = *reinterpret_cast<const u32x4*>(in + ((long)(b * a.H + iy) * a.W + ix) * CIN + cv * 8);
+        for (int k = 0; k < HV; ++k) {
+            const int v = tid + 512 * k;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (v < HP * VPP) {
+                const int hp = v / VPP, cv = v % VPP;
+                const int iy = y0 - 1 + hp / HWD, ix = x0 - 1 + hp % HWD;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    val = *reinterpret_cast<const u32x4*>(in + ((long)(b * a.H + iy) * a.W + ix) * CIN + cv * 8);
+            }
+            hreg[k] = val;
         }
-        hreg[k] = val;
-    }
+    };
+    auto store_halo = [&]() {
 #pragma unroll
-    for (int k = 0; k < HV; ++k) {
-        const int v = tid + 256 * k;
-        if (v < HP * VPP) *reinterpret_cast<u32x4*>(halo + (v / VPP) * RS + (v % VPP) * 16) = hreg[k];
-    }
-    store_w(0);
-    __syncthreads();
+        for (int k = 0; k < HV; ++k) {
+            const int v = tid + 512 * k;
+            if (v < HP * VPP) *reinterpret_cast<u32x4*>(halo + (v / VPP) * RS + (v % VPP) * 16) = hreg[k];
+        }
+    };
 
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    int hp0[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int pl = (wave * TM + i) * 32 + r;
-        hp0[i] = ((pl / TW + 1) * HWD + (pl % TW) + 1) * RS + 16 * h;
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
+    // wave w owns pixels [32w, 32w+32) of the tile; lane r is pixel 32w + r
+    const int pl = wave * 32 + r;
+    const int hp0 = ((pl / TW + 1) * HWD + (pl % TW) + 1) * RS + 16 * h;
+    const unsigned char* wrow = wlds + r * RS + 16 * h;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_halo(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        store_halo();
+        __syncthreads();                                   // halo (and, first time, weights) visible
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_halo(next);                // in flight under the MFMAs below
+
+        f32x16 acc[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    for (int t = 0; t < a.ntaps; ++t) {
-        if (t + 1 < a.ntaps) load_w(t + 1);
-        const int toff = ((int)a.dy[t] * HWD + (int)a.dx[t]) * RS;
-        const unsigned char* wb = wbuf + (t & 1) * WB + r * RS + 16 * h;
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int toff = ((int)a.dy[t] * HWD + (int)a.dx[t]) * RS;
+            const unsigned char* wt = wrow + t * WTAP;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 av[TM], bv[TN];
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 pv = *reinterpret_cast<const bf16x8*>(halo + hp0 + toff + 32 * s);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(halo + hp0[i] + toff + 32 * s);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(wb + j * 32 * RS + 32 * s);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wt + j * 32 * RS + 32 * s);
+                    // D[i = out channel][j = pixel]: each lane ends up with 4 consecutive channels per register quad
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, pv, acc[j], 0, 0, 0);
+                }
+            }
         }
-        if (t + 1 < a.ntaps) store_w((t + 1) & 1);
-        __syncthreads();
-    }
 
-    // ---- epilogue ------------------------------------------------------------------------------
-    if (a.out_f32) {
-        // narrow fp32 outputs (the 3-channel decoder heads): direct stores
-        float* op = reinterpret_cast<float*>(a.out);
+        // ---- epilogue straight from registers: lane = pixel, register quad g = channels 8g + 4h .. +3 ----
+        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / tiles_per_img;
+        const long pix = (long)(b * a.H + ty * TH + pl / TW) * a.W + tx * TW + pl % TW;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + j * 32 + r;
-            if (n >= a.NS) continue;
-            const bool live = n < a.N;
-            const float sc = (live && a.scale) ? a.scale[n] : 1.f;
-            const float sh = (live && a.shift) ? a.shift[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int g = 0; g < 4; ++g) {
+                const int nl = j * 32 + 8 * g + 4 * h;         // first of 4 consecutive local channels
+                const int nn = n0 + nl;
+                if (nn >= a.NS) continue;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ssl + nl);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + NT + nl);
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int pl = (wave * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const long o = ((long)(b * a.H + y0 + pl / TW) * a.W + x0 + pl % TW) * a.NS + n;
-                    float v = acc[i][j][e] * sc + sh;
-                    if (a.res) v += reinterpret_cast<const float*>(a.res)[o];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (!live) v = 0.f;
-                    if (a.accumulate) v += op[o];
-                    op[o] = v;
+                for (int k = 0; k < 4; ++k) v[k] = acc[j][4 * g + k] * sc[k] + sh[k];
+                const long o = pix * a.NS + nn;
+                if (a.out_f32) {
+                    float* op = reinterpret_cast<float*>(a.out);
+                    if (a.res) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.res) + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
+                    if (a.accumulate) {
+                        const f32x4 ov = *reinterpret_cast<const f32x4*>(op + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += ov[k];
+                    }
+                    f32x4 st4 = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(op + o) = st4;
+                } else {
+                    bf16* op = reinterpret_cast<bf16*>(a.out);
+                    if (a.res) {
+                        float rv[4];
+                        Act<bf16>::load4(reinterpret_cast<const bf16*>(a.res) + o, rv);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
+                    if (a.accumulate) {
+                        float ov[4];
+                        Act<bf16>::load4(op + o, ov);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += ov[k];
+                    }
+                    Act<bf16>::store4(op + o, v);
                 }
+            }
         }
-        return;
+        __syncthreads();                                   // every wave is done reading this halo
     }
-    bf16* stage = reinterpret_cast<bf16*>(smem);     // [256 pixels][NT]; the halo is dead after the last barrier
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 32 + r;
-        const bool live = n < a.N;
-        const float sc = (live && a.scale) ? a.scale[n] : 1.f;
-        const float sh = (live && a.shift) ? a.shift[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int pl = (wave * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                stage[pl * NT + j * 32 + r] = (bf16)(live ? acc[i][j][e] * sc + sh : 0.f);
-            }
-    }
-    __syncthreads();
-    constexpr int OV = NT / 8;                       // 16-byte vectors per staged pixel
-    bf16* out = reinterpret_cast<bf16*>(a.out);
-    const bf16* res = reinterpret_cast<const bf16*>(a.res);
-    for (int v = tid; v < 256 * OV; v += 256) {
-        const int pl = v / OV, ov = v % OV;
-        const int nn = n0 + ov * 8;
-        if (nn >= a.NS) continue;
-        const long o = ((long)(b * a.H + y0 + pl / TW) * a.W + x0 + pl % TW) * a.NS + nn;
-        bf16x8 sv = *reinterpret_cast<const bf16x8*>(stage + pl * NT + ov * 8);
-        if (res || a.relu || a.accumulate) {
-            float f[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = (float)sv[k];
-            if (res) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + o);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) f[k] += (float)rv[k];
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
-            }
-            if (a.accumulate) {
-                const bf16x8 ov8 = *reinterpret_cast<const bf16x8*>(out + o);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) f[k] += (float)ov8[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sv[k] = (bf16)f[k];
-        }
-        *reinterpret_cast<bf16x8*>(out + o) = sv;
-    }
+}
+
+template <int CIN, int NT, int TW>
+static constexpr int halo_lds_bytes() {
+    return 9 * NT * (CIN * 2 + 16) + (256 / TW + 2) * (TW + 2) * (CIN * 2 + 16) + 2 * NT * 4;
 }
 
 // true if the plan was launched on the halo kernel
@@ -223,7 +204,6 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     if (P.CgS != 32 && P.CgS != 64) return false;
     const int TW = (P.Wout % 32 == 0) ? 32 : ((P.Wout % 16 == 0) ? 16 : 0);
     if (!TW || P.Hout % (256 / TW)) return false;
-    if (out_f32 && (res || P.NS > 32)) return false;
     HaloArgs a;
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift; a.res = res;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
@@ -231,10 +211,19 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     a.tiles_x = P.Wout / TW; a.tiles_y = P.Hout / (256 / TW);
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
     const int NT = (P.Npad % 64 == 0) ? 64 : 32;
-    dim3 grid(a.tiles_x * a.tiles_y * P.B, P.Npad / NT), block(256);
+    const int ntiles = a.tiles_x * a.tiles_y * P.B;
+    // one persistent workgroup per CU (its LDS footprint allows no more); tiles are strided over the grid
+    dim3 grid(ntiles < 256 ? ntiles : 256, P.Npad / NT), block(512);
 #define HALO_CASE(C, N, T)                                                                                   \
     if (P.CgS == C && NT == N && TW == T) {                                                                  \
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<C, N, T>), grid, block, 0, st, a);                         \
+        constexpr int lds = halo_lds_bytes<C, N, T>();                                                       \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16_kernel<C, N, T>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<C, N, T>), grid, block, lds, st, a);                       \
         return true;                                                                                         \
     }
     HALO_CASE(64, 64, 32) HALO_CASE(64, 32, 32) HALO_CASE(32, 64, 32) HALO_CASE(32, 32, 32)
