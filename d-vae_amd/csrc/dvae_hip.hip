@@ -329,20 +329,25 @@ int dvae_reparam_kl_fwd(const float* mulv, const float* eps, void* z1, float* kl
     if (rows <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");
     if (!eps) DVAE_FAIL(DVAE_EINVAL, "reparam: eps is NULL (use dvae_reparam_kl_fwd_philox to draw in-kernel)");
     PhiloxKey key = {nullptr, 0, 0u, 0u, 0u};
-    DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), mulv, eps,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T, float>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), mulv, eps,
                                          (float*)nullptr, (T*)z1, kl_partial, rows, L, rows, key);)
     DVAE_CHECK_LAUNCH("reparam_kl_fwd");
     return DVAE_OK;
 }
 
-int dvae_reparam_kl_fwd_philox(const float* mulv, float* eps_out, void* z1, float* kl_partial, int B, int rows_per_image,
-                               int L, const int32_t* index, int64_t first, uint64_t seed, uint32_t stream_id, int dtype,
-                               void* st) {
+int dvae_reparam_kl_fwd_philox(const void* mulv, int mulv_is_act, float* eps_out, void* z1, float* kl_partial, int B,
+                               int rows_per_image, int L, const int32_t* index, int64_t first, uint64_t seed,
+                               uint32_t stream_id, int dtype, void* st) {
     if (B <= 0 || rows_per_image <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");
     PhiloxKey key = {index, (long)first, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id};
-    DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), mulv,
-                                         (const float*)nullptr, eps_out, (T*)z1, kl_partial, B * rows_per_image, L,
-                                         rows_per_image, key);)
+    if (mulv_is_act && dtype == DVAE_BF16) {
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16, bf16>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), (const bf16*)mulv,
+                           (const float*)nullptr, eps_out, (bf16*)z1, kl_partial, B * rows_per_image, L, rows_per_image, key);
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<T, float>), dim3(DVAE_NPARTIAL), dim3(256), 0, S(st),
+                                             (const float*)mulv, (const float*)nullptr, eps_out, (T*)z1, kl_partial,
+                                             B * rows_per_image, L, rows_per_image, key);)
+    }
     DVAE_CHECK_LAUNCH("reparam_kl_fwd_philox");
     return DVAE_OK;
 }

@@ -142,12 +142,12 @@ __device__ inline f32x4 philox_normal4(const PhiloxKey& k, uint64_t img, uint32_
     float n[4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        // Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sin/v_cos (argument in turns)
         const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
         const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
-        const float rad = sqrtf(-2.0f * logf(u1));
-        float sn, cs;
-        sincosf(6.283185307179586f * u2, &sn, &cs);
-        n[2 * h] = rad * cs; n[2 * h + 1] = rad * sn;
+        const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+        n[2 * h] = rad * __builtin_amdgcn_cosf(u2);
+        n[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
     f32x4 v = {n[0], n[1], n[2], n[3]};
     return v;
@@ -169,8 +169,9 @@ __global__ void philox_normal_kernel(float* out, int B, int per_image, const Phi
 // ------------------------------------------------------------------------------------------------
 // eps == NULL: the noise is drawn in-kernel (same Philox stream as philox_normal_kernel for an
 // [image][row][channel] tensor) and, when eps_out != NULL, stored for the backward pass.
-template <typename T>
-__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, const float* eps, float* eps_out, T* z1,
+// TMV: element type of mulv (fp32, or the act dtype on the inference path where no loss is taken).
+template <typename T, typename TMV>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const TMV* mulv, const float* eps, float* eps_out, T* z1,
                                                              float* kl_partial, int rows, int L, int rows_per_image,
                                                              const PhiloxKey key) {
     __shared__ float red[4];
@@ -180,8 +181,9 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long row = i / LV;
         const int c = (int)(i % LV) * 4;
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mulv + row * 2 * L + c);
-        const f32x4 lv = *reinterpret_cast<const f32x4*>(mulv + row * 2 * L + L + c);
+        float mu[4], lv[4];
+        Act<TMV>::load4(mulv + row * 2 * L + c, mu);
+        Act<TMV>::load4(mulv + row * 2 * L + L + c, lv);
         f32x4 e;
         if (eps) {
             e = *reinterpret_cast<const f32x4*>(eps + row * L + c);

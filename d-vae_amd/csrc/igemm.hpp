@@ -210,7 +210,8 @@ constexpr int LDS_ROW = 144;   // bytes per staged tile row: 128 B of K data + 1
 template <typename T> struct Mfma;
 template <> struct Mfma<float> {
     // 128-byte K slab = 32 floats.  v_mfma_f32_32x32x2_f32: lane (r = l&31, h = l>>5) supplies
-    // A[r][k=h] and B[k=h][r].  Each lane reads 4 consecutive floats at column 8q+4h, so MFMA e of
+    // A[r][k=h] and B[k=h][r].  The weight fragment goes in as A and the pixel fragment as B, so the
+    // result tile is D[channel][pixel]: lane r owns one pixel and each register quad 4 consecutive channels.  Each lane reads 4 consecutive floats at column 8q+4h, so MFMA e of
     // group q contracts columns {8q+e, 8q+4+e}; A and B use the same map, the sum is unchanged.
     __device__ static inline void run(const unsigned char* arow, const unsigned char* brow, int h, f32x16& acc) {
 #pragma unroll
@@ -218,7 +219,7 @@ template <> struct Mfma<float> {
             f32x4 a = *reinterpret_cast<const f32x4*>(arow + 32 * q + 16 * h);
             f32x4 b = *reinterpret_cast<const f32x4*>(brow + 32 * q + 16 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], a[e], acc, 0, 0, 0);
         }
     }
 };
@@ -231,7 +232,7 @@ template <> struct Mfma<bf16> {
         for (int s = 0; s < 4; ++s) {
             bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + 32 * s + 16 * h);
             bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * s + 16 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc, 0, 0, 0);
         }
     }
 };
@@ -340,34 +341,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    // epilogue: lane holds column n = ..+r and rows (e&3) + 8*(e>>2) + 4*h of each 32x32 tile
+    // epilogue: lane r owns pixel wm0 + 32i + r; register quad g of tile j holds channels
+    // n0 + wn0 + 32j + 8g + 4h .. +3 -> 16-byte (fp32) / 8-byte (bf16) channel runs per store
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + 32 * j + r;
-        if (n >= a.NS) continue;
-        const bool live = n < a.N;
-        const float sc = (live && a.scale) ? a.scale[n] : 1.f;
-        const float sh = (live && a.shift) ? a.shift[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int dp = rowdst[wm0 + 32 * i + r];
+        if (dp < 0) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ml = wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int dp = rowdst[ml];
-                if (dp < 0) continue;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + 32 * j + 8 * g + 4 * h;
+                if (n >= a.NS) continue;
                 const long o = (long)dp * a.NS + n;
-                float v = acc[i][j][e] * sc + sh;
-                if (a.res) v += (float)reinterpret_cast<const T*>(a.res)[o];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (!live) v = 0.f;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool live = n + k < a.N;
+                    const float sc = (live && a.scale) ? a.scale[n + k] : 1.f;
+                    const float sh = (live && a.shift) ? a.shift[n + k] : 0.f;
+                    v[k] = live ? acc[i][j][4 * g + k] * sc + sh : 0.f;
+                }
+                if (a.res) {
+                    float rv[4];
+                    Act<T>::load4(reinterpret_cast<const T*>(a.res) + o, rv);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (n + k >= a.N) v[k] = 0.f;
                 if (a.out_f32) {
                     float* op = reinterpret_cast<float*>(a.out);
-                    if (a.accumulate) v += op[o];
-                    op[o] = v;
+                    if (a.accumulate) {
+                        float ov[4];
+                        Act<float>::load4(op + o, ov);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += ov[k];
+                    }
+                    Act<float>::store4(op + o, v);
                 } else {
                     T* op = reinterpret_cast<T*>(a.out);
-                    if (a.accumulate) v += (float)op[o];
-                    op[o] = (T)v;
+                    if (a.accumulate) {
+                        float ov[4];
+                        Act<T>::load4(op + o, ov);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += ov[k];
+                    }
+                    Act<T>::store4(op + o, v);
                 }
             }
         }

@@ -487,13 +487,17 @@ class DVAEEngine:
         if not self.packed_valid:
             self.pack_weights()
         h = self.h
-        mulv = self.act("mulv", h, 2 * self.Ld, f32=True)
-        self._conv("fc", stem_out, mulv, b, shift=self.param["fc.bias"], out_f32=True)
+        # Inference with in-kernel noise takes no loss from mu / log_var: they stay in the act dtype there
+        # (halves the largest tensor of the forward pass on the bf16 path).  Training keeps them fp32.
+        lean = isinstance(eps, PhiloxEps) and not keep_eps and self.dtype == BF16
+        mulv = self.act("mulv.act", h, 2 * self.Ld) if lean else self.act("mulv", h, 2 * self.Ld, f32=True)
+        self._conv("fc", stem_out, mulv, b, shift=self.param["fc.bias"], out_f32=not lean)
         z1 = self.act("z1", h, self.Ld)
         if isinstance(eps, PhiloxEps):
             eps_out = self.buf("eps", (self.B, h, h, self.Ld), torch.float32) if keep_eps else None
-            check(self.lib.dvae_reparam_kl_fwd_philox(ptr(mulv), ptr(eps_out), ptr(z1), ptr(self.kl_partial), b, h * h, self.Ld,
-                                                      ptr(eps.index), eps.first, self.seed, eps.stream_id, self.dtype, L.stream()))
+            check(self.lib.dvae_reparam_kl_fwd_philox(ptr(mulv), int(lean), ptr(eps_out), ptr(z1), ptr(self.kl_partial), b, h * h,
+                                                      self.Ld, ptr(eps.index), eps.first, self.seed, eps.stream_id, self.dtype,
+                                                      L.stream()))
         else:
             check(self.lib.dvae_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z1), ptr(self.kl_partial), b * h * h, self.Ld,
                                                self.dtype, L.stream()))

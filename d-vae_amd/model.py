@@ -69,6 +69,8 @@ class _PathFunction(torch.autograd.Function):
         L.check(eng.lib.dvae_recon_loss_fwd(L.ptr(rec_pre), L.ptr(p), L.ptr(x0), L.ptr(rec_act), L.ptr(eng.recon_partial),
                                             b * S * S, eng.dtype, L.stream()))
         mulv = eng.act("mulv", h, 2 * Ld, f32=True)
+        if eps is None and not train and eng.dtype == L.BF16:
+            mulv = eng.act("mulv.act", h, 2 * Ld)       # inference keeps mu / log_var in the act dtype
         rec = eng.to_nchw(rec_act, b, 3, S)
         pert = eng.to_nchw(p, b, 3, S)
         mu = eng.to_nchw(mulv, b, Ld, h, 0)

@@ -135,8 +135,9 @@ int dvae_reparam_kl_fwd(const float* mulv, const float* eps, void* z1, float* kl
                         int rows, int L, int dtype, void* stream);
 /* same, with eps drawn in-kernel from the Philox stream of dvae_philox_normal for an [image][rows][L]
  * tensor; eps_out (or NULL) receives it for the backward pass. */
-int dvae_reparam_kl_fwd_philox(const float* mulv, float* eps_out, void* z1, float* kl_partial, int B, int rows_per_image,
-                               int L, const int32_t* image_index /* [B] or NULL */, int64_t first_image, uint64_t seed,
+int dvae_reparam_kl_fwd_philox(const void* mulv, int mulv_is_act /* mulv stored in the act dtype (inference) */,
+                               float* eps_out, void* z1, float* kl_partial, int B, int rows_per_image, int L,
+                               const int32_t* image_index /* [B] or NULL */, int64_t first_image, uint64_t seed,
                                uint32_t stream_id, int dtype, void* stream);
 int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal,
                         void* dmulv, int rows, int L, int dtype, void* stream);
