@@ -25,6 +25,8 @@ struct HaloArgs {
     const float* scale;
     const float* shift;
     const void* res;
+    const float* in_ss;      // optional input normalisation [B][2][CIN]: x <- relu?(x * scale + shift) while staging
+    int in_relu;
     int B, H, W, N, NS, Ktot;
     int relu, accumulate, out_f32, ntaps;
     int tiles_x, tiles_y;
@@ -67,9 +69,18 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     }
 
     u32x4 hreg[HV];
+    unsigned inimg = 0;                                   // bit k: hreg[k] is a pixel inside the image
+    f32x4 isc[2], ish[2];                                 // input normalisation of this thread's 8 channels
+    static_assert(512 % VPP == 0, "a thread keeps one channel group across its halo vectors");
     auto load_halo = [&](int tile) {
         const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / tiles_per_img;
         const int y0 = ty * TH, x0 = tx * TW;
+        inimg = 0;
+        if (a.in_ss) {
+            const float* p = a.in_ss + (long)b * 2 * CIN + (tid % VPP) * 8;
+            isc[0] = *reinterpret_cast<const f32x4*>(p); isc[1] = *reinterpret_cast<const f32x4*>(p + 4);
+            ish[0] = *reinterpret_cast<const f32x4*>(p + CIN); ish[1] = *reinterpret_cast<const f32x4*>(p + CIN + 4);
+        }
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             const int v = tid + 512 * k;
@@ -77,8 +88,10 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
             if (v < HP * VPP) {
                 const int hp = v / VPP, cv = v % VPP;
                 const int iy = y0 - 1 + hp / HWD, ix = x0 - 1 + hp % HWD;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
                     val = *reinterpret_cast<const u32x4*>(in + ((long)(b * a.H + iy) * a.W + ix) * CIN + cv * 8);
+                    inimg |= 1u << k;
+                }
             }
             hreg[k] = val;
         }
@@ -87,7 +100,19 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             const int v = tid + 512 * k;
-            if (v < HP * VPP) *reinterpret_cast<u32x4*>(halo + (v / VPP) * RS + (v % VPP) * 16) = hreg[k];
+            if (v >= HP * VPP) continue;
+            u32x4 val = hreg[k];
+            if (a.in_ss && (inimg >> k & 1u)) {           // zero padding stays zero: it pads the normalised tensor
+                bf16x8 x = *reinterpret_cast<bf16x8*>(&val);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float f = (float)x[c] * isc[c >> 2][c & 3] + ish[c >> 2][c & 3];
+                    if (a.in_relu) f = fmaxf(f, 0.f);
+                    x[c] = (bf16)f;
+                }
+                val = *reinterpret_cast<u32x4*>(&x);
+            }
+            *reinterpret_cast<u32x4*>(halo + (v / VPP) * RS + (v % VPP) * 16) = val;
         }
     };
 
@@ -191,9 +216,22 @@ static constexpr int halo_lds_bytes() {
 }
 
 // true if the plan was launched on the halo kernel
+static bool halo_applicable(const GemmPlan& P) {
+    if (P.nphase != 1) return false;
+    const Phase& ph = P.ph[0];
+    if (ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return false;
+    if (P.Hin != P.Hout || P.Win != P.Wout || ph.Hg != P.Hout || ph.Wg != P.Wout) return false;
+    if (ph.ntaps < 1 || ph.ntaps > 9) return false;
+    for (int t = 0; t < ph.ntaps; ++t)
+        if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return false;
+    if (P.CgS != 32 && P.CgS != 64) return false;
+    const int TW = (P.Wout % 32 == 0) ? 32 : ((P.Wout % 16 == 0) ? 16 : 0);
+    return TW && P.Hout % (256 / TW) == 0;
+}
+
 static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                  const float* shift, const void* res, int relu, int accumulate, int out_f32,
-                                 hipStream_t st) {
+                                 hipStream_t st, const float* in_ss = nullptr, int in_relu = 0) {
     if (P.nphase != 1) return false;
     const Phase& ph = P.ph[0];
     if (ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return false;
@@ -206,6 +244,7 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     if (!TW || P.Hout % (256 / TW)) return false;
     HaloArgs a;
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift; a.res = res;
+    a.in_ss = in_ss; a.in_relu = in_relu;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32; a.ntaps = ph.ntaps;
     a.tiles_x = P.Wout / TW; a.tiles_y = P.Hout / (256 / TW);

@@ -117,15 +117,25 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
     int rc = build_plan(*d, DVAE_OP_FWD, dtype, P);
     if (rc) return rc;
-    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0};
+    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
     if (ep) e = *ep;
+    if (e.in_scale_shift && (dtype != DVAE_BF16 || !halo_applicable(P)))
+        DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation is not available for this shape/dtype "
+                               "(see dvae_conv_supports_input_norm)");
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
-    if (try_launch_halo_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+    if (try_launch_halo_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), e.in_scale_shift,
+                             e.in_relu)) {
         DVAE_CHECK_LAUNCH("conv_halo");
         return DVAE_OK;
     }
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
+}
+
+int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype) {
+    GemmPlan P;
+    if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P)) return 0;
+    return halo_applicable(P) ? 1 : 0;
 }
 
 int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, const dvae_conv_desc* d, int dtype,
@@ -234,6 +244,23 @@ int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* ga
                hipLaunchKernelGGL((norm_apply_kernel<T>), dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, S(st),
                                   (const T*)x, (const T*)res, (T*)y, scale_shift, rows_per_group, C, nvec, relu);)
     DVAE_CHECK_LAUNCH("norm_apply");
+    return DVAE_OK;
+}
+
+int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                        float* scale_shift, void* ws, size_t ws_bytes, int groups, int rows_per_group, int C, float eps,
+                        int dtype, void* st) {
+    int rc = norm_check(groups, rows_per_group, C, dtype);
+    if (rc) return rc;
+    const NormGeom g = norm_geom(groups, rows_per_group, C);
+    if (ws_bytes < norm_ws_floats(g) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "norm workspace too small");
+    float* partial = (float*)ws;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((norm_stats_kernel<T>), dim3(g.nchunk, groups), dim3(256), 0, S(st), (const T*)x,
+                                         partial, rows_per_group, C, g.rows_per_chunk, g.nchunk);)
+    DVAE_CHECK_LAUNCH("norm_stats");
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), partial, g.nchunk, C, gamma,
+                       beta, (float*)nullptr, (float*)nullptr, save_mean, save_invstd, scale_shift, 0.f, eps);
+    DVAE_CHECK_LAUNCH("norm_finalize");
     return DVAE_OK;
 }
 

@@ -178,29 +178,36 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const TMV* mulv, co
     const int LV = L / 4;
     const long total = (long)rows * LV;
     float acc = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long row = i / LV;
-        const int c = (int)(i % LV) * 4;
-        float mu[4], lv[4];
-        Act<TMV>::load4(mulv + row * 2 * L + c, mu);
-        Act<TMV>::load4(mulv + row * 2 * L + L + c, lv);
-        f32x4 e;
-        if (eps) {
-            e = *reinterpret_cast<const f32x4*>(eps + row * L + c);
-        } else {
-            const int b = (int)(row / rows_per_image);
-            const long in_img = (row % rows_per_image) * L + c;
-            const uint64_t img = key.index ? (uint64_t)key.index[b] : (uint64_t)(key.first + b);
-            e = philox_normal4(key, img, (uint32_t)(in_img >> 2));
-            if (eps_out) *reinterpret_cast<f32x4*>(eps_out + row * L + c) = e;
-        }
-        float z[4];
+    // two independent 4-channel groups per iteration keep more bytes in flight per lane
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 2 * stride) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            z[k] = e[k] * expf(0.5f * lv[k]) + mu[k];
-            acc += 1.f + lv[k] - mu[k] * mu[k] - expf(lv[k]);
+        for (int u = 0; u < 2; ++u) {
+            const long i = i0 + u * stride;
+            if (i >= total) break;
+            const long row = i / LV;
+            const int c = (int)(i % LV) * 4;
+            float mu[4], lv[4];
+            Act<TMV>::load4(mulv + row * 2 * L + c, mu);
+            Act<TMV>::load4(mulv + row * 2 * L + L + c, lv);
+            f32x4 e;
+            if (eps) {
+                e = *reinterpret_cast<const f32x4*>(eps + row * L + c);
+            } else {
+                const int b = (int)(row / rows_per_image);
+                const long in_img = (row % rows_per_image) * L + c;
+                const uint64_t img = key.index ? (uint64_t)key.index[b] : (uint64_t)(key.first + b);
+                e = philox_normal4(key, img, (uint32_t)(in_img >> 2));
+                if (eps_out) *reinterpret_cast<f32x4*>(eps_out + row * L + c) = e;
+            }
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                z[k] = e[k] * expf(0.5f * lv[k]) + mu[k];
+                acc += 1.f + lv[k] - mu[k] * mu[k] - expf(lv[k]);
+            }
+            Act<T>::store4(z1 + row * L + c, z);
         }
-        Act<T>::store4(z1 + row * L + c, z);
     }
     const float s = block_sum_256(acc, red);
     if (threadIdx.x == 0) kl_partial[blockIdx.x] = -0.5f * s;

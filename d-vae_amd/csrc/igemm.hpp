@@ -420,7 +420,11 @@ static int launch_igemm(const GemmPlan& P, const void* in, const void* wp, void*
     if (maxM == 0) return DVAE_OK;
     constexpr int BM = 128;
     dim3 block(256);
-    if (P.Npad % 128 == 0) {
+    if (P.Npad % 256 == 0 && sizeof(T) == 2) {
+        // wide outputs (mu|log_var: N = 2L): a 128 x 256 tile halves the re-gathering of the A rows
+        dim3 grid((maxM + BM - 1) / BM, P.Npad / 256, P.nphase);
+        hipLaunchKernelGGL((igemm_kernel<T, 2, 4, 2, 2>), grid, block, 0, st, a);
+    } else if (P.Npad % 128 == 0) {
         dim3 grid((maxM + BM - 1) / BM, P.Npad / 128, P.nphase);
         hipLaunchKernelGGL((igemm_kernel<T, 2, 2, 2, 2>), grid, block, 0, st, a);
     } else if (P.Npad % 64 == 0) {

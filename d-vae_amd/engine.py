@@ -225,6 +225,8 @@ class DVAEEngine:
         self._alloc_workspaces()
         self.fold_valid = False
         self.packed_valid = False
+        self._fuse_in = all(self.lib.dvae_conv_supports_input_norm(C.byref(self._desc(self.specs[n], 1)), dtype)
+                            for n in ("decoder2.0", "decoder3.0"))
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
 
     # ------------------------------------------------------------------------------------------
@@ -327,8 +329,8 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     # primitive launches
     # ------------------------------------------------------------------------------------------
-    def _conv(self, name, x, y, b, scale=None, shift=None, residual=None, relu=False, out_f32=False):
-        ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32))
+    def _conv(self, name, x, y, b, scale=None, shift=None, residual=None, relu=False, out_f32=False, in_ss=None, in_relu=False):
+        ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu))
         pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
         if pr:
             pr[1][0].record()
@@ -424,8 +426,8 @@ class DVAEEngine:
         _, _, z = self.latent(stem_out, eps, b, keep_eps=train)
         if isinstance(eps, PhiloxEps):
             eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
-        rec_pre = self._decoder("decoder", z, b)
-        p = self.perturb(stem_out, z, y, b)
+        rec_pre = self._decoder("decoder", z, b, train)
+        p = self.perturb(stem_out, z, y, b, train)
         self._last = dict(b=b, x0=x0, y=y, eps=eps, stem_out=stem_out, train=train)
         return rec_pre, p
 
@@ -505,7 +507,7 @@ class DVAEEngine:
         self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"])
         return mulv, z1, z
 
-    def perturb(self, stem_out, z, y, b):
+    def perturb(self, stem_out, z, y, b, train=True):
         """decoder_p(Embedding + stem_out | Embedding + z | Embedding), resnet.py:2211-2221."""
         cfg, h = self.cfg, self.h
         ep = self.act("dec_p.in", h, 128)
@@ -514,23 +516,42 @@ class DVAEEngine:
             add = stem_out if cfg.use_y else z
         check(self.lib.dvae_emb_add_fwd(ptr(self.emb_table), ptr(y), ptr(add), ptr(ep), b, h * h, 128,
                                         int(cfg.spatial_emb), self.dtype, L.stream()))
-        return self._decoder("decoder_p", ep, b)
+        return self._decoder("decoder_p", ep, b, train)
 
-    def _decoder(self, d, zin, b):
+    def _decoder(self, d, zin, b, train=True):
+        """ConvT(k4,s2) -> ConvT(k3) -> IN+ReLU -> ConvT(k3) -> IN+ReLU -> ConvT(k3)  (resnet.py:2011-2050).
+        Training keeps every intermediate for backward.  Inference (where the consuming conv supports it)
+        computes only the InstanceNorm statistics and lets the next conv normalise its input while staging
+        it: the normalised maps d3 / d5 are never written."""
         S = self.S
         d1 = self.act(d + ".d1", S, 64)
         self._conv(d + "1.0", zin, d1, b, shift=self.param[d + "1.0.bias"])
         d2 = self.act(d + ".d2", S, 64)
         self._conv(d + "1.1", d1, d2, b, shift=self.param[d + "1.1.bias"])
+        d4 = self.act(d + ".d4", S, 32)
+        d6 = self.act(d + ".d6", S, 3, f32=True)       # rec_pre / perturbation stay fp32 on every path
+        fuse = (not train) and self._fuse_in
+        if fuse:
+            ss1 = self._in_stats(d + ".in1", d2, b, 64)
+            self._conv(d + "2.0", d2, d4, b, shift=self.param[d + "2.0.bias"], in_ss=ss1, in_relu=True)
+            ss2 = self._in_stats(d + ".in2", d4, b, 32)
+            self._conv(d + "3.0", d4, d6, b, shift=self.param[d + "3.0.bias"], out_f32=True, in_ss=ss2, in_relu=True)
+            return d6
         d3 = self.act(d + ".d3", S, 64)
         self._in_fwd(d + ".in1", d2, d3, b, 64)
-        d4 = self.act(d + ".d4", S, 32)
         self._conv(d + "2.0", d3, d4, b, shift=self.param[d + "2.0.bias"])
         d5 = self.act(d + ".d5", S, 32)
         self._in_fwd(d + ".in2", d4, d5, b, 32)
-        d6 = self.act(d + ".d6", S, 3, f32=True)       # rec_pre / perturbation stay fp32 on every path
         self._conv(d + "3.0", d5, d6, b, shift=self.param[d + "3.0.bias"], out_f32=True)
         return d6
+
+    def _in_stats(self, tag, x, b, c):
+        mean = self.buf(tag + ".mean", (self.B, c), torch.float32)
+        invstd = self.buf(tag + ".invstd", (self.B, c), torch.float32)
+        ss = self.buf(tag + ".ss", (self.B, 2, c), torch.float32)
+        check(self.lib.dvae_norm_fwd_stats(ptr(x), None, None, ptr(mean), ptr(invstd), ptr(ss), ptr(self.norm_ws),
+                                           self.norm_ws.numel() * 4, b, self.S * self.S, c, IN_EPS, self.dtype, L.stream()))
+        return ss
 
     # ------------------------------------------------------------------------------------------
     # losses

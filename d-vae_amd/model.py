@@ -278,7 +278,7 @@ class ResNetDVAE(nn.Module):
         e = eng.eps_from_nchw(eps) if eps is not None else eng.eps_philox(b, first=self._draws * b, stream_id=7)
         self._draws += 1
         mulv, _, z = eng.latent(a, e, b, keep_eps=False)
-        rec_pre = eng._decoder("decoder", z, b)
+        rec_pre = eng._decoder("decoder", z, b, self.training)
         rec = torch.sigmoid(eng.to_nchw(rec_pre, b, 3, eng.S))
         return rec, eng.to_nchw(mulv, b, eng.Ld, h, 0), eng.to_nchw(mulv, b, eng.Ld, h, eng.Ld), eng.to_nchw(z, b, 128, h)
 

@@ -59,6 +59,12 @@ typedef struct dvae_epilogue {
     const void* residual;     /* act tensor shaped like the output, or NULL */
     int32_t relu;
     int32_t out_f32;          /* write fp32 (channel padding of the fp32 rule) even when dtype is bf16: mu|log_var, rec_pre, p */
+    /* Optional fused prologue (inference): the input is normalised per image and channel while it is staged,
+     * x <- relu?(x * scale[b][c] + shift[b][c]), with in_scale_shift = [B][2][Cin] fp32 as dvae_norm_fwd_stats
+     * produces it (InstanceNorm2d + ReLU folded into the consuming conv).  Only where
+     * dvae_conv_supports_input_norm() says so; NULL = off. */
+    const float* in_scale_shift;
+    int32_t in_relu;
 } dvae_epilogue;
 
 const char* dvae_version(void);
@@ -85,6 +91,7 @@ int dvae_conv_pack_job(const float* w_ref, void* w_packed, const dvae_conv_desc*
 int dvae_conv_pack_batch(const void* jobs_dev, int njobs, int dtype, void* stream);
 int dvae_conv_fwd(const void* x, const void* w_packed_fwd, const dvae_epilogue* ep, void* y,
                   const dvae_conv_desc* d, int dtype, void* stream);
+int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype);
 int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int accumulate,
                     const dvae_conv_desc* d, int dtype, void* stream);
 size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);
@@ -103,6 +110,11 @@ int dvae_norm_fwd_train(const void* x, const void* residual, void* y,
                         void* workspace, size_t workspace_bytes,
                         int groups, int rows_per_group, int C, int relu,
                         float momentum, float eps, int dtype, void* stream);
+/* statistics only: save_mean / save_invstd and scale_shift [groups][2][C] (scale = gamma * invstd, shift = beta -
+ * mean * scale), for a consumer that applies the normalisation itself (dvae_epilogue.in_scale_shift) */
+int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                        float* scale_shift, void* workspace, size_t workspace_bytes, int groups, int rows_per_group,
+                        int C, float eps, int dtype, void* stream);
 int dvae_bn_fwd_eval(const void* x, const void* residual, void* y,
                      const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                      float* scale_shift /* [2][C] scratch */, int rows, int C, int relu, float eps,
