@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--purify-batch", type=int, default=1024)
     ap.add_argument("--train-batch", type=int, default=128)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="activation / MFMA input type (accumulation, statistics, losses, optimiser are fp32 either way)")
     ap.add_argument("--images", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
@@ -171,6 +172,26 @@ def main():
         return
     peak = PEAK_TFLOPS[a.dtype]
     probe_tflops = 2.0 * CONV_PROBE_MACS * Bp / (probe_avg * 1e-3) / 1e12
+    # Roofline of the dominant kernel, the 3x3 64->64 conv at 32x32.  Algorithmic work per image: 2 * 37 748 736
+    # FLOP and (read x + write y) = 2 * 64 ch * 1024 px * element size bytes.  fp32: 144 FLOP/B against a ridge of
+    # 157.3 T / 8 T = 20 -> MFMA-bound.  bf16: 288 FLOP/B against a ridge of 2500 / 8 = 312 -> HBM-bound (just).
+    esz = 4 if a.dtype == "f32" else 2
+    probe_bytes = 2.0 * 64 * 1024 * esz * Bp
+    probe_gbs = probe_bytes / (probe_avg * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{a.dtype}.json")
+    if os.path.exists(tpath) and Bp == 1024:
+        traffic = json.load(open(tpath)).get("hbm_bytes")     # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch
+    kname = "conv_halo_bf16_kernel<64,64,32>" if a.dtype == "bf16" else "igemm_kernel<float,2,1,2,2>"
+    if a.dtype == "bf16":
+        roof = {"bound": "hbm", "achieved": probe_gbs, "peak": 8000.0, "unit": "GB/s", "frac": probe_gbs / 8000.0,
+                "mfma_tflops": probe_tflops, "mfma_frac": probe_tflops / peak}
+    else:
+        roof = {"bound": "mfma", "achieved": probe_tflops, "peak": peak, "unit": "TFLOP/s", "frac": probe_tflops / peak,
+                "hbm_gbs": probe_gbs}
+    roof.update(kernel=f"{kname} ({CONV_PROBE}: 3x3 conv 64->64 @32x32, {Bp} images/launch)", avg_launch_ms=probe_avg,
+                launches_timed=len(probe_ms), algorithmic_bytes_per_launch=probe_bytes,
+                algorithmic_flops_per_launch=2.0 * CONV_PROBE_MACS * Bp, traffic=traffic)
     res = {
         "metric": "purified images/sec (node) + VAE train imgs/sec, CIFAR-10 shape",
         "value": purify_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -182,9 +203,7 @@ def main():
         "train_images_per_sec": train_ips, "train_ms_per_step": train_ms, "allgather_ms": allgather_ms,
         "purify_tflops": 2.0 * 2 * FWD_MACS * purify_ips / 1e12,
         "train_tflops": (2.0 * TRAIN_MACS * train_ips / 1e12) if train_ips else None,
-        "roofline": {"bound": "mfma", "kernel": f"igemm_kernel ({CONV_PROBE}: 3x3 conv 64->64 @32x32, {Bp} images/launch)",
-                     "achieved": probe_tflops, "peak": peak, "unit": "TFLOP/s", "frac": probe_tflops / peak,
-                     "avg_launch_ms": probe_avg, "launches_timed": len(probe_ms), "traffic": None},
+        "roofline": roof,
     }
     if not a.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(1024)
