@@ -3,16 +3,24 @@
 // The gather GEMM of igemm.hpp re-reads every input pixel once per tap (9x for a 3x3 conv) through
 // L2; at bf16 MFMA rates that traffic, not the matrix pipe, bounds it.  Here one workgroup owns a
 // TH x TW patch of output pixels (256 pixels) of one image, stages the (TH+2) x (TW+2) input halo in
-// LDS once (zero-filled outside the image), and forms the A fragment of every tap by re-addressing
-// that tile: lane r of a 32-pixel MFMA row block reads halo pixel (py+dy, px+dx) -- consecutive
-// lanes hit consecutive 144-byte (64 ch) / 80-byte (32 ch) pixel rows, conflict-free for
-// ds_read_b128.  Workgroups are persistent (one per CU, 8 waves): the weights of every tap stay in LDS for the
-// workgroup's lifetime, tiles are strided over the grid, and the next tile's halo is fetched into
-// registers while the current tile's MFMAs run, so a tile costs two barriers and no weight traffic.
-// The MFMA is issued as D[channel][pixel] = W * X^T: each lane then owns one pixel and register
-// quads of 4 consecutive channels, so the epilogue (scale/shift, residual, ReLU, accumulate) reads and
-// writes 8-byte (bf16) / 16-byte (fp32) channel runs straight from registers, no LDS staging.
-// Serves every single-phase radius-1 unit-stride plan: Conv2d 3x3 s1 forward and input-gradient, ConvTranspose2d 3x3 s1 forward and input-gradient (the plan supplies the taps).
+// LDS once (zero-filled outside the image), and forms the pixel fragment of every tap by re-addressing
+// that tile: lane r of a 32-pixel MFMA block reads halo pixel (py+dy, px+dx) -- consecutive
+// lanes hit consecutive 144-byte (64 ch) / 80-byte (32 ch) pixel rows, conflict-free for ds_read_b128.
+//
+// Workgroups are persistent (one per CU, 8 waves).  The weights of all nine taps stay in LDS for the
+// workgroup's lifetime (unpadded rows, 16-byte chunks XOR-swizzled by the row index so that the 32 rows
+// a fragment read touches spread over all banks).  A CU's vector-memory path moves 64 B/clk, so the ~110 KB a
+// tile reads and writes would cost as much as its MFMAs if issued in a burst; instead every global access
+// of a tile is issued from inside the fully unrolled MFMA loop, one instruction every few MFMAs:
+//   - the previous tile's output, parked as bf16 in the wave's private LDS patch, is drained to HBM as whole
+//     128-byte pixel rows (the MFMA leaves a lane with 4-channel quads of one pixel; the patch transposes);
+//   - this tile's residual / old output rows are fetched (coalesced), to be re-read from the patch in
+//     register layout after the loop and added in fp32, so the result is rounded once;
+//   - the next tile's halo is fetched into registers.
+// A tile therefore costs two barriers, no weight traffic, and no burst on the memory path.
+// The MFMA is issued as D[channel][pixel] = W * X^T (lane = pixel, register quad = 4 consecutive channels).
+// Serves every single-phase 9-tap radius-1 unit-stride plan: Conv2d 3x3 s1 forward and input-gradient,
+// ConvTranspose2d 3x3 s1 forward and input-gradient (the plan supplies the taps).
 #pragma once
 #include "igemm.hpp"
 
@@ -24,11 +32,11 @@ struct HaloArgs {
     void* out;
     const float* scale;
     const float* shift;
-    const void* res;
+    const void* add;         // bf16 tensor shaped like the output: residual (added before the ReLU) or the old output
     const float* in_ss;      // optional input normalisation [B][2][CIN]: x <- relu?(x * scale + shift) while staging
     int in_relu;
     int B, H, W, N, NS, Ktot;
-    int relu, accumulate, out_f32;
+    int relu, add_after_relu, out_f32;
     int lx, ly;              // log2 of the tile counts per image row / column (both powers of two)
     signed char dy[16], dx[16];
     unsigned long long* stamps;   // profiling aid: [grid.x][64 tiles][8] cycle-counter samples of wave 0, or null
@@ -44,15 +52,21 @@ struct HaloArgs {
 template <int CIN, int NT, int TW>
 __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     constexpr int TH = 256 / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
-    constexpr int RS = CIN * 2 + 16;          // bytes per staged pixel / weight row (16-byte pad spreads banks)
-    constexpr int VPP = CIN * 2 / 16;         // 16-byte vectors per pixel
+    constexpr int RS = CIN * 2 + 16;          // bytes per staged halo pixel (16-byte pad spreads banks)
+    constexpr int WR = CIN * 2;               // bytes per weight row (swizzled, unpadded)
+    constexpr int VPP = CIN * 2 / 16;         // 16-byte vectors per pixel / weight row
+    constexpr int WSH = (CIN == 64) ? 1 : 2;  // weight rows per 256-byte bank row, log2: swizzle key = (row >> WSH) & (VPP - 1)
     constexpr int HALO_BYTES = HP * RS;
-    constexpr int WTAP = NT * RS;             // one tap's weight slab
+    constexpr int WTAP = NT * WR;             // one tap's weight slab
     constexpr int TN = NT / 32, KS = CIN / 16, NSTEP = 9 * KS;
     constexpr int HV = (HP * VPP + 511) / 512;
-    // persistent workgroup: all taps' weights stay in LDS, one halo tile at a time, next tile's halo in registers
+    // epilogue patch of one wave: 32 pixels x NT channels bf16, padded rows
+    constexpr int SRS = NT * 2 + 16, VPS = NT / 8, PPI = 64 / VPS, NI = 32 / PPI;
+    // global accesses of a tile, spread over the MFMA steps: NI+1 drain slots, NI add fetches, HV halo fetches
+    constexpr int NOPS = 2 * NI + 1 + HV, OPSTRIDE = NSTEP / NOPS;
+    static_assert(OPSTRIDE >= 1, "more memory operations than MFMA steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* wlds = smem;                                  // [9][NT][RS]
+    unsigned char* wlds = smem;                                  // [9][NT][WR]
     unsigned char* halo = smem + 9 * WTAP;                       // [HP][RS]
     float* ssl = reinterpret_cast<float*>(smem + 9 * WTAP + HALO_BYTES);   // scale[NT], shift[NT]
 
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     // ---- weights (every tap) and the epilogue's per-channel scale/shift -> LDS, once -----------------
     for (int v = tid; v < 9 * NT * VPP; v += 512) {
         const int t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, cv = rem % VPP;
-        *reinterpret_cast<u32x4*>(wlds + t * WTAP + n * RS + cv * 16) =
+        *reinterpret_cast<u32x4*>(wlds + t * WTAP + n * WR + ((cv ^ ((n >> WSH) & (VPP - 1))) * 16)) =
             *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + cv * 8);
     }
     if (tid < NT) {
@@ -92,26 +106,27 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     }
     unsigned inimg = 0;                                   // bit k: hreg[k] is a pixel inside the image
     f32x4 isc[2], ish[2];                                 // input normalisation of this thread's 8 channels
-    auto load_halo = [&](int tile) {
-        const int tx = tile & mx, ty = (tile >> a.lx) & my, b = tile >> (a.lx + a.ly);
-        const int y0 = ty * TH, x0 = tx * TW;
-        const bf16* org = in + ((long)(b * a.H + y0) * a.W + x0) * CIN;
-        inimg = 0;
-        if (a.in_ss) {
-            const float* p = a.in_ss + (long)b * 2 * CIN + (tid % VPP) * 8;
-            isc[0] = *reinterpret_cast<const f32x4*>(p); isc[1] = *reinterpret_cast<const f32x4*>(p + 4);
-            ish[0] = *reinterpret_cast<const f32x4*>(p + CIN); ish[1] = *reinterpret_cast<const f32x4*>(p + CIN + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < HV; ++k) {
-            u32x4 val = {0u, 0u, 0u, 0u};
-            const int iy = y0 - 1 + (hyx[k] >> 16), ix = x0 - 1 + (hyx[k] & 0xffff);
-            if (hyx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-                val = *reinterpret_cast<const u32x4*>(org + hrel[k]);
-                inimg |= 1u << k;
+    auto tile_origin = [&](int tile, int& y0, int& x0, int& b) {
+        x0 = (tile & mx) * TW; y0 = ((tile >> a.lx) & my) * TH; b = tile >> (a.lx + a.ly);
+    };
+    auto load_halo_vec = [&](int tile, int k) {           // k-th vector of `tile`'s halo -> hreg[k]
+        int y0, x0, b;
+        tile_origin(tile, y0, x0, b);
+        if (k == 0) {
+            inimg = 0;
+            if (a.in_ss) {
+                const float* p = a.in_ss + (long)b * 2 * CIN + (tid % VPP) * 8;
+                isc[0] = *reinterpret_cast<const f32x4*>(p); isc[1] = *reinterpret_cast<const f32x4*>(p + 4);
+                ish[0] = *reinterpret_cast<const f32x4*>(p + CIN); ish[1] = *reinterpret_cast<const f32x4*>(p + CIN + 4);
             }
-            hreg[k] = val;
         }
+        u32x4 val = {0u, 0u, 0u, 0u};
+        const int iy = y0 - 1 + (hyx[k] >> 16), ix = x0 - 1 + (hyx[k] & 0xffff);
+        if (hyx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            val = *reinterpret_cast<const u32x4*>(in + ((long)(b * a.H + y0) * a.W + x0) * CIN + hrel[k]);
+            inimg |= 1u << k;
+        }
+        hreg[k] = val;
     };
     auto store_halo = [&]() {
 #pragma unroll
@@ -137,15 +152,17 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     // wave w owns pixels [32w, 32w+32) of the tile; lane r is pixel 32w + r
     const int pl = wave * 32 + r;
     const unsigned char* hrow = halo + ((pl / TW + 1) * HWD + (pl % TW) + 1) * RS + 16 * h;
-    const unsigned char* wrow = wlds + r * RS + 16 * h;
-    // this wave's epilogue patch: 32 pixels x 32 channels (bf16, one MFMA column block at a time), 80-byte rows
-    constexpr int SRS = 32 * 2 + 16;
+    int woff[KS];                                         // this lane's swizzled chunk of weight row r, per 16-channel slab
+#pragma unroll
+    for (int sl = 0; sl < KS; ++sl) woff[sl] = r * WR + (((2 * sl + h) ^ ((r >> WSH) & (VPP - 1))) * 16);
     unsigned char* stg = smem + 9 * WTAP + HALO_BYTES + 2 * NT * 4 + wave * (32 * SRS);
-    const int sp = lane >> 2, sc8 = lane & 3;             // coalesced side: lane = (pixel sp of 16, 8-channel chunk sc8 of 4)
-    auto out_off = [&](int tile, int j, int i) -> long {  // element offset of this lane's 16-byte piece of the output tile
-        const int tx = tile & mx, ty = (tile >> a.lx) & my, b = tile >> (a.lx + a.ly);
-        const int p = wave * 32 + i * 16 + sp;
-        return ((long)(b * a.H + ty * TH + p / TW) * a.W + tx * TW + p % TW) * a.NS + n0 + j * 32 + sc8 * 8;
+    const int sp = lane / VPS, sc8 = lane % VPS;          // coalesced side: lane = (pixel sp of a PPI group, 8-channel chunk sc8)
+    const bool chunk_live = n0 + sc8 * 8 < a.NS;
+    auto out_off = [&](int tile, int i) -> long {         // element offset of this lane's 16-byte piece i of the output tile
+        int y0, x0, b;
+        tile_origin(tile, y0, x0, b);
+        const int p = wave * 32 + i * PPI + sp;
+        return ((long)(b * a.H + y0 + p / TW) * a.W + x0 + p % TW) * a.NS + n0 + sc8 * 8;
     };
     auto wave_lds_fence = [&]() {                          // LDS hand-over between lanes of one wave: order, no barrier
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -157,34 +174,42 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         const int t = st / KS, sl = st % KS;
         pv = *reinterpret_cast<const bf16x8*>(hrow + toff[t] + 32 * sl);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wv[j] = *reinterpret_cast<const bf16x8*>(wrow + t * WTAP + j * 32 * RS + 32 * sl);
+        for (int j = 0; j < TN; ++j) wv[j] = *reinterpret_cast<const bf16x8*>(wlds + woff[sl] + t * WTAP + j * 32 * WR);
     };
+    const bool staged = !a.out_f32;
+    bf16* outb = reinterpret_cast<bf16*>(a.out);
+    const bf16* addb = reinterpret_cast<const bf16*>(a.add);
 
     int tile = blockIdx.x;
-    if (tile < ntiles) load_halo(tile);
-    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    if (tile < ntiles) {
+#pragma unroll
+        for (int k = 0; k < HV; ++k) load_halo_vec(tile, k);
+    }
+    int it = 0;
+    for (; tile < ntiles; tile += gridDim.x, ++it) {
         HALO_STAMP(0);
         store_halo();
         HALO_STAMP(1);
         __syncthreads();                                   // halo (and, first time, weights) visible
         HALO_STAMP(2);
-        const int next = tile + gridDim.x;
-        if (next < ntiles) load_halo(next);                // in flight under the MFMAs below
-        u32x4 rres[TN][2], racc[TN][2];
-        if (!a.out_f32 && (a.res || a.accumulate)) {       // coalesced, and in flight under the MFMAs too
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const bool live = n0 + j * 32 + sc8 * 8 < a.NS;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const long o = out_off(tile, j, i);
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    rres[j][i] = (a.res && live) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(a.res) + o) : z;
-                    racc[j][i] = (a.accumulate && live) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(a.out) + o) : z;
+        const int next = tile + gridDim.x, prev = tile - gridDim.x;
+        const bool drain = staged && it > 0, fetch_add = staged && a.add != nullptr, fetch_next = next < ntiles;
+        u32x4 radd[NI], dreg;
+        // q-th global access of this tile (compile-time q): drain reads/stores, add fetches, halo fetches
+        auto mem_op = [&](int q) {
+            if (q <= NI) {
+                if (drain) {
+                    if (q > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(prev, q - 1)) = dreg;
+                    if (q < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16);
                 }
+            } else if (q <= 2 * NI) {
+                const int i = q - NI - 1;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                radd[i] = (fetch_add && chunk_live) ? *reinterpret_cast<const u32x4*>(addb + out_off(tile, i)) : z;
+            } else {
+                if (fetch_next) load_halo_vec(next, q - 2 * NI - 1);
             }
-        }
-        HALO_STAMP(3);
+        };
 
         f32x16 acc[TN];
 #pragma unroll
@@ -198,18 +223,21 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 if (st + 1 < NSTEP) frag(st + 1, pv[(st + 1) & 1], wv[(st + 1) & 1]);
+                if (st % OPSTRIDE == 0 && st / OPSTRIDE < NOPS) mem_op(st / OPSTRIDE);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     // D[i = out channel][j = pixel]: each lane ends up with 4 consecutive channels per register quad
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[st & 1][j], pv[st & 1], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);         // keep the memory operations where they were placed
             }
         }
-
         HALO_STAMP(4);
+
         if (a.out_f32) {
-            const int tx = tile & mx, ty = (tile >> a.lx) & my, b = tile >> (a.lx + a.ly);
             // ---- fp32 output (narrow decoder heads): straight from registers, lane = pixel, quad g = channels 8g+4h.. ----
-            const long pix = (long)(b * a.H + ty * TH + pl / TW) * a.W + tx * TW + pl % TW;
+            int y0, x0, b;
+            tile_origin(tile, y0, x0, b);
+            const long pix = (long)(b * a.H + y0 + pl / TW) * a.W + x0 + pl % TW;
             float* op = reinterpret_cast<float*>(a.out);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -224,8 +252,8 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[j][4 * g + k] * sc[k] + sh[k];
                     const long o = pix * a.NS + nn;
-                    if (a.res) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.res) + o);
+                    if (a.add && !a.add_after_relu) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.add) + o);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] += rv[k];
                     }
@@ -233,8 +261,8 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                     }
-                    if (a.accumulate) {
-                        const f32x4 ov = *reinterpret_cast<const f32x4*>(op + o);
+                    if (a.add && a.add_after_relu) {
+                        const f32x4 ov = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.add) + o);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] += ov[k];
                     }
@@ -243,9 +271,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
                 }
             }
         } else {
-            // ---- bf16 output through this wave's private LDS patch: registers hold (pixel = lane, 4-channel quads), global
-            // memory wants whole pixel rows.  Residual / old output arrive as coalesced 16-byte vectors (fetched before the
-            // MFMAs), are re-read from the patch in register layout and added in fp32, so rounding happens once. ----
+            // ---- bf16 output: finish in registers, park in the wave's LDS patch; the next tile's MFMA loop drains it ----
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -256,55 +282,58 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc[j][4 * g + k] = acc[j][4 * g + k] * sc[k] + sh[k];
                 }
-            bf16* op = reinterpret_cast<bf16*>(a.out);
+            auto add_staged = [&]() {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                auto add_staged = [&](const u32x4 (&src)[2]) {
+                for (int i = 0; i < NI; ++i)
+                    *reinterpret_cast<u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16) = radd[i];
+                wave_lds_fence();
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        *reinterpret_cast<u32x4*>(stg + (i * 16 + sp) * SRS + sc8 * 16) = src[i];
-                    wave_lds_fence();
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const bf16x4 q = *reinterpret_cast<const bf16x4*>(stg + r * SRS + (8 * g + 4 * h) * 2);
+                        const bf16x4 q = *reinterpret_cast<const bf16x4*>(stg + r * SRS + (j * 32 + 8 * g + 4 * h) * 2);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[j][4 * g + k] += (float)q[k];
                     }
-                    wave_lds_fence();
-                };
-                if (a.res) add_staged(rres[j]);
-                if (a.relu) {
+                wave_lds_fence();
+            };
+            if (a.add && !a.add_after_relu) add_staged();
+            if (a.relu) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
-                }
-                if (a.accumulate) add_staged(racc[j]);
+            }
+            if (a.add && a.add_after_relu) add_staged();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 q;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) q[k] = (bf16)acc[j][4 * g + k];
-                    *reinterpret_cast<bf16x4*>(stg + r * SRS + (8 * g + 4 * h) * 2) = q;
+                    *reinterpret_cast<bf16x4*>(stg + r * SRS + (j * 32 + 8 * g + 4 * h) * 2) = q;
                 }
-                wave_lds_fence();
-                if (n0 + j * 32 + sc8 * 8 < a.NS) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        *reinterpret_cast<u32x4*>(op + out_off(tile, j, i)) =
-                            *reinterpret_cast<const u32x4*>(stg + (i * 16 + sp) * SRS + sc8 * 16);
-                }
-                wave_lds_fence();
-            }
+            wave_lds_fence();
         }
         HALO_STAMP(5);
         __syncthreads();                                   // every wave is done reading this halo
         HALO_STAMP(6);
+    }
+    // ---- the last tile's output is still parked in the patch ----
+    if (staged && it > 0 && chunk_live) {
+        const int last = tile - gridDim.x;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<u32x4*>(outb + out_off(last, i)) =
+                *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
     }
 }
 #undef HALO_STAMP
 
 static constexpr int halo_lds_bytes_of(int CIN, int NT, int TW) {
     // weights of 9 taps + one halo tile + epilogue scale/shift + the 8 waves' output patches
-    return 9 * NT * (CIN * 2 + 16) + (256 / TW + 2) * (TW + 2) * (CIN * 2 + 16) + 2 * NT * 4 + 8 * 32 * 80;
+    return 9 * NT * (CIN * 2) + (256 / TW + 2) * (TW + 2) * (CIN * 2 + 16) + 2 * NT * 4 + 8 * 32 * (NT * 2 + 16);
 }
 template <int CIN, int NT, int TW>
 static constexpr int halo_lds_bytes() { return halo_lds_bytes_of(CIN, NT, TW); }
@@ -344,10 +373,12 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     const Phase& ph = P.ph[0];
     const int TW = hg.TW, NT = hg.NT;
     HaloArgs a;
-    a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift; a.res = res;
+    if (res && accumulate) return false;                  // one additive operand per launch
+    a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift;
+    a.add = res ? res : (accumulate ? out : nullptr); a.add_after_relu = accumulate ? 1 : 0;
     a.in_ss = in_ss; a.in_relu = in_relu; a.stamps = stamps;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
-    a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+    a.relu = relu; a.out_f32 = out_f32;
     a.lx = ilog2_exact(P.Wout / TW); a.ly = ilog2_exact(P.Hout / (256 / TW));
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
     const int ntiles = P.B << (a.lx + a.ly);

@@ -38,17 +38,17 @@ int main(int argc, char** argv) {
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
     std::vector<unsigned long long> hs(256 * 64 * 8);
     hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-    const char* names[6] = {"store_halo", "barrier1", "issue next halo loads", "mfma loop", "epilogue", "barrier2"};
+    const char* names[6] = {"store_halo", "barrier1", "mfma loop + global accesses", "", "epilogue", "barrier2"};
     const int tiles_per_wg = B * 4 / 256;
     double sum[7] = {0}; long cnt = 0;
     for (int g = 0; g < 256; ++g)
         for (int it = 1; it < tiles_per_wg && it < 64; ++it) {    // skip the first tile (weights staging)
             const unsigned long long* s = &hs[((size_t)g * 64 + it) * 8];
-            for (int k = 0; k < 6; ++k) sum[k] += (double)(s[k + 1] - s[k]);
+            for (int k = 0; k < 6; ++k) sum[k] += (k == 3) ? 0.0 : (double)(s[k == 2 ? 4 : k + 1] - s[k]);
             sum[6] += (double)(s[6] - s[0]);
             ++cnt;
         }
-    for (int k = 0; k < 6; ++k) printf("  %-24s %8.0f cycles\n", names[k], sum[k] / cnt);
+    for (int k = 0; k < 6; ++k) if (k != 3) printf("  %-28s %8.0f ticks\n", names[k], sum[k] / cnt);
     printf("  %-24s %8.0f cycles per tile (%ld samples)\n", "total", sum[6] / cnt, cnt);
     const unsigned long long* s0 = &hs[0];
     printf("  wg0: first tile %llu cycles, whole kernel %llu cycles\n", s0[6] - s0[0],
