@@ -341,6 +341,99 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
+    if constexpr (sizeof(T) == 2) {
+        if (!a.out_f32) {
+            // ---- bf16 output through this wave's private LDS patch (the K-loop's tiles are dead after its last
+            // barrier): the MFMA leaves a lane with 4-channel quads of one pixel, global memory wants whole
+            // channel runs.  32 pixels x 32*TN channels at a time; residual / old output come in as coalesced
+            // 16-byte vectors, are re-read in register layout and added in fp32, so the result is rounded once.
+            constexpr int SRS = TN * 64 + 16, VPS = TN * 4, PPI = 64 / VPS, NI = 32 / PPI;
+            static_assert(4 * 32 * SRS <= (BM + BN) * LDS_ROW, "epilogue patches must fit in the tile buffers");
+            unsigned char* stg = smem + wave * (32 * SRS);
+            const int sp = lane / VPS, sc8 = lane % VPS;
+            const int nc = n0 + wn0 + sc8 * 8;               // first channel of this lane's 16-byte piece
+            const T* resb = reinterpret_cast<const T*>(a.res);
+            T* outb = reinterpret_cast<T*>(a.out);
+            auto wave_lds_fence = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                long orow[NI];                               // element offset of this lane's piece, or -1
+#pragma unroll
+                for (int q = 0; q < NI; ++q) {
+                    const int dp = rowdst[wm0 + 32 * i + q * PPI + sp];
+                    orow[q] = (dp >= 0 && nc < a.NS) ? (long)dp * a.NS + nc : -1;
+                }
+                u32x4 radd[NI], rold[NI];
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                if (a.res) {
+#pragma unroll
+                    for (int q = 0; q < NI; ++q) radd[q] = orow[q] >= 0 ? *reinterpret_cast<const u32x4*>(resb + orow[q]) : z;
+                }
+                if (a.accumulate) {
+#pragma unroll
+                    for (int q = 0; q < NI; ++q) rold[q] = orow[q] >= 0 ? *reinterpret_cast<const u32x4*>(outb + orow[q]) : z;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn0 + 32 * j + 8 * g + 4 * h;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool live = n + k < a.N;
+                            const float sc = (live && a.scale) ? a.scale[n + k] : 1.f;
+                            const float sh = (live && a.shift) ? a.shift[n + k] : 0.f;
+                            acc[i][j][4 * g + k] = live ? acc[i][j][4 * g + k] * sc + sh : 0.f;
+                        }
+                    }
+                auto add_staged = [&](const u32x4 (&src)[NI]) {
+#pragma unroll
+                    for (int q = 0; q < NI; ++q)
+                        *reinterpret_cast<u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16) = src[q];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const bf16x4 qd = *reinterpret_cast<const bf16x4*>(stg + r * SRS + (32 * j + 8 * g + 4 * h) * 2);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[i][j][4 * g + k] += (float)qd[k];
+                        }
+                    wave_lds_fence();
+                };
+                if (a.res) add_staged(radd);
+                if (a.relu) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+                }
+                if (a.accumulate) add_staged(rold);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn0 + 32 * j + 8 * g + 4 * h;
+                        bf16x4 qd;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) qd[k] = (bf16)((n + k < a.N) ? acc[i][j][4 * g + k] : 0.f);   // pad channels stay zero
+                        *reinterpret_cast<bf16x4*>(stg + r * SRS + (32 * j + 8 * g + 4 * h) * 2) = qd;
+                    }
+                wave_lds_fence();
+#pragma unroll
+                for (int q = 0; q < NI; ++q) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16);
+                    if (orow[q] >= 0) *reinterpret_cast<u32x4*>(outb + orow[q]) = val;
+                }
+                wave_lds_fence();
+            }
+            return;
+        }
+    }
     // epilogue: lane r owns pixel wm0 + 32i + r; register quad g of tile j holds channels
     // n0 + wn0 + 32j + 8g + 4h .. +3 -> 16-byte (fp32) / 8-byte (bf16) channel runs per store
 #pragma unroll
