@@ -379,6 +379,24 @@ int dvae_reparam_kl_fwd_philox(const void* mulv, int mulv_is_act, float* eps_out
     return DVAE_OK;
 }
 
+int dvae_fc_reparam_supported(const dvae_conv_desc* d, int L, int dtype) {
+    GemmPlan P;
+    if (!d || dtype != DVAE_BF16 || L <= 0 || build_plan(*d, DVAE_OP_FWD, dtype, P)) return 0;
+    return zf_applicable(P, L) ? 1 : 0;
+}
+
+int dvae_fc_reparam_fwd_philox(const void* x, const void* wp, const float* bias, void* z, const dvae_conv_desc* d, int L,
+                               const int32_t* index, int64_t first, uint64_t seed, uint32_t stream_id, int dtype,
+                               void* st) {
+    GemmPlan P;
+    if (!d || !x || !wp || !z) DVAE_FAIL(DVAE_EINVAL, "fc_reparam: null argument");
+    if (dtype != DVAE_BF16) DVAE_FAIL(DVAE_EDTYPE, "fc_reparam: bf16 only (see dvae_fc_reparam_supported)");
+    int rc = build_plan(*d, DVAE_OP_FWD, dtype, P);
+    if (rc) return rc;
+    PhiloxKey key = {index, (long)first, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id};
+    return launch_igemm_zf(P, x, wp, bias, z, L, key, S(st));
+}
+
 int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal, void* dmulv, int rows,
                         int L, int dtype, void* st) {
     if (rows <= 0 || L <= 0 || L % 4) DVAE_FAIL(DVAE_EINVAL, "reparam: L must be a positive multiple of 4");

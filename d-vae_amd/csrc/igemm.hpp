@@ -17,6 +17,7 @@
 // order and scatters into the reference's weight layout (deterministic, no float atomics).
 #pragma once
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace dvae {
 
@@ -203,6 +204,9 @@ struct GemmArgs {
     int Ktot;
     int relu, accumulate, out_f32;
     Phase ph[4];
+    // fused encoder head (ZF kernels only): out = z [rows][zL] = eps * exp(lv / 2) + mu with (mu | lv) = this GEMM's 2*zL columns
+    int zL, zrpi;            // latent channels; GEMM rows per image (the Philox counter restarts per image)
+    PhiloxKey zkey;
 };
 
 constexpr int LDS_ROW = 144;   // bytes per staged tile row: 128 B of K data + 16 B pad (bank spread)
@@ -237,7 +241,18 @@ template <> struct Mfma<bf16> {
     }
 };
 
-template <typename T, int TM, int TN, int WGM, int WGN>
+// ZF (fused encoder head, 1x1 GEMM with N = 2*zL columns [mu | log_var]): the weight rows are taken in an order that
+// gives every wave 16*TN latent channels as TN/2 column blocks of mu followed by the same channels' log_var, so a
+// lane holds mu and log_var of the same channel quad; the epilogue draws eps, forms z and writes only z.
+// Column cl of N-tile t (BN columns = BN/2 latent channels) reads weight row zrow(t, cl).
+template <int BN, int WGN, int TN>
+__device__ __forceinline__ int zf_row(int t, int cl, int zL) {
+    constexpr int WC = BN / WGN;                 // GEMM columns per wave
+    const int w = cl / WC, jj = (cl % WC) / (WC / 2), c = cl % (WC / 2);
+    return jj * zL + t * (BN / 2) + w * (WC / 2) + c;
+}
+
+template <typename T, int TM, int TN, int WGM, int WGN, bool ZF = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     constexpr int BM = WGM * 32 * TM, BN = WGN * 32 * TN;
     constexpr int VEC = 16 / sizeof(T);
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDS_ROW];
     __shared__ int rowdst[BM];
     __shared__ int taptab[16];
+    __shared__ __attribute__((aligned(16))) float ssl[2 * BN];   // epilogue scale[BN], shift[BN] (0, 0 on pad channels)
     unsigned char* As = smem;
     unsigned char* Bs = smem + BM * LDS_ROW;
 
@@ -258,6 +274,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     const int kvec = tid & 7, lrow = tid >> 3;
 
     if (tid < 16) taptab[tid] = ((int)ph.dy[tid] << 16) | ((int)ph.dx[tid] & 0xffff);
+    for (int c = tid; c < BN; c += 256) {
+        const int n = ZF ? zf_row<BN, WGN, TN>(blockIdx.y, c, a.zL) : n0 + c;
+        const bool live = n < a.N;
+        ssl[c] = live ? (a.scale ? a.scale[n] : 1.f) : 0.f;
+        ssl[BN + c] = (live && a.shift) ? a.shift[n] : 0.f;
+    }
     if (tid < BM) {
         const int m = m0 + tid;
         int dst = -1;
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const int n = n0 + lrow + 32 * i;
+            const int n = ZF ? zf_row<BN, WGN, TN>(blockIdx.y, lrow + 32 * i, a.zL) : n0 + lrow + 32 * i;
             breg[i] = *reinterpret_cast<const u32x4*>(wp + (long)n * a.Ktot + k);
         }
     };
@@ -341,6 +363,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
+    if constexpr (ZF) {
+        // ---- fused encoder head: lane (pixel r, quad g of column block j < TN/2) holds mu in acc[i][j] and log_var in
+        // acc[i][j + TN/2]; z goes through the wave's LDS patch so that global memory sees whole channel runs ----
+        static_assert(sizeof(T) == 2 && TN % 2 == 0, "fused encoder head: bf16, mu and log_var column blocks");
+        constexpr int ZC = 16 * TN;                          // latent channels per wave
+        constexpr int SRS = ZC * 2 + 16, VPS = ZC / 8, PPI = 64 / VPS, NI = 32 / PPI;
+        static_assert(4 * 32 * SRS <= (BM + BN) * LDS_ROW, "epilogue patches must fit in the tile buffers");
+        unsigned char* stg = smem + wave * (32 * SRS);
+        const int sp = lane / VPS, sc8 = lane % VPS;
+        const int zc0 = blockIdx.y * (BN / 2) + (wave % WGN) * ZC;   // first latent channel of this wave
+        T* outb = reinterpret_cast<T*>(a.out);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = rowdst[wm0 + 32 * i + r];        // 1x1 unit-stride GEMM: output pixel == GEMM row
+            const int rr = row < 0 ? 0 : row;
+            const int b = rr / a.zrpi;
+            const uint64_t img = a.zkey.index ? (uint64_t)a.zkey.index[b] : (uint64_t)(a.zkey.first + b);
+            const long in_img = (long)(rr % a.zrpi) * a.zL;
+#pragma unroll
+            for (int j = 0; j < TN / 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = 32 * j + 8 * g + 4 * h;   // channel within the wave's ZC
+                    const int nl = wn0 + cl;                 // tile column of mu; log_var sits ZC columns further
+                    const f32x4 bm = *reinterpret_cast<const f32x4*>(ssl + BN + nl);
+                    const f32x4 bl = *reinterpret_cast<const f32x4*>(ssl + BN + nl + ZC);
+                    const f32x4 e = philox_normal4(a.zkey, img, (uint32_t)((in_img + zc0 + cl) >> 2));
+                    bf16x4 qd;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float mu = acc[i][j][4 * g + k] + bm[k], lv = acc[i][j + TN / 2][4 * g + k] + bl[k];
+                        qd[k] = (bf16)(e[k] * __expf(0.5f * lv) + mu);
+                    }
+                    *reinterpret_cast<bf16x4*>(stg + r * SRS + cl * 2) = qd;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int dp = rowdst[wm0 + 32 * i + q * PPI + sp];
+                const u32x4 val = *reinterpret_cast<const u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16);
+                if (dp >= 0) *reinterpret_cast<u32x4*>(outb + (long)dp * a.zL + zc0 + sc8 * 8) = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
+    }
     if constexpr (sizeof(T) == 2) {
         if (!a.out_f32) {
             // ---- bf16 output through this wave's private LDS patch (the K-loop's tiles are dead after its last
@@ -381,14 +453,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int n = n0 + wn0 + 32 * j + 8 * g + 4 * h;
+                        const int nl = wn0 + 32 * j + 8 * g + 4 * h;
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssl + nl);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + BN + nl);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bool live = n + k < a.N;
-                            const float sc = (live && a.scale) ? a.scale[n + k] : 1.f;
-                            const float sh = (live && a.shift) ? a.shift[n + k] : 0.f;
-                            acc[i][j][4 * g + k] = live ? acc[i][j][4 * g + k] * sc + sh : 0.f;
-                        }
+                        for (int k = 0; k < 4; ++k) acc[i][j][4 * g + k] = acc[i][j][4 * g + k] * sc[k] + sh[k];
                     }
                 auto add_staged = [&](const u32x4 (&src)[NI]) {
 #pragma unroll
@@ -448,13 +517,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
                 if (n >= a.NS) continue;
                 const long o = (long)dp * a.NS + n;
                 float v[4];
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ssl + (n - n0));
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + BN + (n - n0));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool live = n + k < a.N;
-                    const float sc = (live && a.scale) ? a.scale[n + k] : 1.f;
-                    const float sh = (live && a.shift) ? a.shift[n + k] : 0.f;
-                    v[k] = live ? acc[i][j][4 * g + k] * sc + sh : 0.f;
-                }
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * sc[k] + sh[k];
                 if (a.res) {
                     float rv[4];
                     Act<T>::load4(reinterpret_cast<const T*>(a.res) + o, rv);
@@ -501,6 +567,7 @@ static int launch_igemm(const GemmPlan& P, const void* in, const void* wp, void*
     // an fp32 output keeps the fp32 channel padding (>= 4) whatever the activation dtype is
     a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+    a.zL = 0; a.zrpi = 1; a.zkey = PhiloxKey{nullptr, 0, 0u, 0u, 0u};
     int maxM = 0;
     for (int i = 0; i < 4; ++i) a.ph[i] = P.ph[i];
     for (int i = 0; i < P.nphase; ++i) {
@@ -528,6 +595,33 @@ static int launch_igemm(const GemmPlan& P, const void* in, const void* wp, void*
         hipLaunchKernelGGL((igemm_kernel<T, 1, 1, 4, 1>), grid, block, 0, st, a);
     }
     DVAE_CHECK_LAUNCH("igemm");
+    return DVAE_OK;
+}
+
+// Fused encoder head: z = eps * exp(log_var / 2) + mu for a 1x1 unit-stride conv whose 2L outputs are [mu | log_var].
+static bool zf_applicable(const GemmPlan& P, int L) {
+    if (P.nphase != 1 || P.N != 2 * L || L % 128) return false;
+    const Phase& ph = P.ph[0];
+    return ph.ntaps == 1 && ph.SY == 1 && ph.SX == 1 && ph.DSY == 1 && ph.DSX == 1 && !ph.D0Y && !ph.D0X &&
+           ph.dy[0] == 0 && ph.dx[0] == 0 && P.Hin == P.Hout && P.Win == P.Wout && ph.Hg == P.Hout && ph.Wg == P.Wout;
+}
+
+static int launch_igemm_zf(const GemmPlan& P, const void* in, const void* wp, const float* bias, void* z, int L,
+                           const PhiloxKey& key, hipStream_t st) {
+    if (!zf_applicable(P, L)) DVAE_FAIL(DVAE_EINVAL, "fc_reparam: needs a 1x1 unit-stride conv with 2L outputs, L a multiple of 128");
+    GemmArgs a;
+    a.in = in; a.wp = wp; a.out = z; a.scale = nullptr; a.shift = bias; a.res = nullptr;
+    a.B = P.B; a.Hin = P.Hin; a.Win = P.Win; a.cg_log2 = P.cg_log2;
+    a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    a.relu = 0; a.accumulate = 0; a.out_f32 = 0;
+    for (int i = 0; i < 4; ++i) a.ph[i] = P.ph[i];
+    a.zL = L; a.zrpi = P.Hout * P.Wout; a.zkey = key;
+    const long M = (long)P.B * P.Hout * P.Wout;
+    if (M > 0x7fffffffL / 2 || M * P.CgS > 0x7fffffffL || M * L > 0x7fffffffL) DVAE_FAIL(DVAE_EINVAL, "tensor exceeds 2^31 elements");
+    if (M == 0) return DVAE_OK;
+    dim3 grid((unsigned)((M + 127) / 128), P.N / 256, 1), block(256);
+    hipLaunchKernelGGL((igemm_kernel<bf16, 2, 4, 2, 2, true>), grid, block, 0, st, a);
+    DVAE_CHECK_LAUNCH("igemm_zf");
     return DVAE_OK;
 }
 

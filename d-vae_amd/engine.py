@@ -227,6 +227,7 @@ class DVAEEngine:
         self.packed_valid = False
         self._fuse_in = all(self.lib.dvae_conv_supports_input_norm(C.byref(self._desc(self.specs[n], 1)), dtype)
                             for n in ("decoder2.0", "decoder3.0"))
+        self._fuse_head = bool(self.lib.dvae_fc_reparam_supported(C.byref(self._desc(self.specs["fc"], 1)), self.Ld, dtype))
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
 
     # ------------------------------------------------------------------------------------------
@@ -423,7 +424,7 @@ class DVAEEngine:
         """x0: input act [B,S,S,4]; y: int64 [b]; eps: fp32 act [B,h,h,L].  Leaves rec_pre / p (and
         every intermediate needed by backward) in the engine's buffers and returns them."""
         stem_out = self.stem(x0, b, train)
-        _, _, z = self.latent(stem_out, eps, b, keep_eps=train)
+        _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train)
         if isinstance(eps, PhiloxEps):
             eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
         rec_pre = self._decoder("decoder", z, b, train)
@@ -483,7 +484,7 @@ class DVAEEngine:
             a = out
         return a
 
-    def latent(self, stem_out, eps, b, keep_eps=True):
+    def latent(self, stem_out, eps, b, keep_eps=True, need_mulv=True):
         """encode (fc_mu|fc_var as one GEMM) -> reparameterise (+ KL partial sums) -> post_conv.
         resnet.py:2197-2199, :2245-2246, :2257-2259."""
         if not self.packed_valid:
@@ -492,9 +493,17 @@ class DVAEEngine:
         # Inference with in-kernel noise takes no loss from mu / log_var: they stay in the act dtype there
         # (halves the largest tensor of the forward pass on the bf16 path).  Training keeps them fp32.
         lean = isinstance(eps, PhiloxEps) and not keep_eps and self.dtype == BF16
+        z1 = self.act("z1", h, self.Ld)
+        if lean and self._fuse_head and not need_mulv:
+            # one launch: mu / log_var never leave the registers of the GEMM that makes them
+            check(self.lib.dvae_fc_reparam_fwd_philox(ptr(stem_out), ptr(self.packed[("fc", L.OP_FWD)]), ptr(self.param["fc.bias"]),
+                                                      ptr(z1), C.byref(self.desc("fc", b)), self.Ld, ptr(eps.index), eps.first,
+                                                      self.seed, eps.stream_id, self.dtype, L.stream()))
+            z = self.act("z", h, 128)
+            self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"])
+            return None, z1, z
         mulv = self.act("mulv.act", h, 2 * self.Ld) if lean else self.act("mulv", h, 2 * self.Ld, f32=True)
         self._conv("fc", stem_out, mulv, b, shift=self.param["fc.bias"], out_f32=not lean)
-        z1 = self.act("z1", h, self.Ld)
         if isinstance(eps, PhiloxEps):
             eps_out = self.buf("eps", (self.B, h, h, self.Ld), torch.float32) if keep_eps else None
             check(self.lib.dvae_reparam_kl_fwd_philox(ptr(mulv), int(lean), ptr(eps_out), ptr(z1), ptr(self.kl_partial), b, h * h,

@@ -153,6 +153,15 @@ int dvae_reparam_kl_fwd_philox(const void* mulv, int mulv_is_act /* mulv stored 
                                uint32_t stream_id, int dtype, void* stream);
 int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal,
                         void* dmulv, int rows, int L, int dtype, void* stream);
+/* Inference encoder head in one launch: the 1x1 conv fc_mu|fc_var (resnet.py:2245-2246; packed forward weights of
+ * a conv with 2L outputs, mu rows first, bias fp32 [2L]) and the reparameterisation (resnet.py:2257-2259) with eps
+ * drawn in-kernel from the Philox stream of dvae_philox_normal.  Writes only z [B*H*W][L] in the act dtype; mu and
+ * log_var stay in registers (fp32).  No KL sums: the purification pass (main_vae_disentangle.py:45-95) takes no
+ * loss.  dvae_fc_reparam_supported tells whether (desc, L, dtype) can run here (bf16, 1x1 unit stride, L % 128 == 0). */
+int dvae_fc_reparam_supported(const dvae_conv_desc* d, int L, int dtype);
+int dvae_fc_reparam_fwd_philox(const void* x, const void* wp, const float* bias, void* z, const dvae_conv_desc* d,
+                               int L, const int32_t* image_index /* [B] or NULL */, int64_t first_image,
+                               uint64_t seed, uint32_t stream_id, int dtype, void* stream);
 
 /* ---- reconstruction losses (main_vae_disentangle.py:190-192, :205-207) -----------------------
  * rec_pre and p (the decoders' 3-channel outputs, written by dvae_conv_fwd with out_f32) are fp32

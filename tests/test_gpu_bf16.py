@@ -195,3 +195,40 @@ def test_conv_bf16_fused_epilogue_and_accumulate():
     L.check(lib.dvae_conv_dgrad(to_act(gy, L.BF16).data_ptr(), pkd.data_ptr(), dxa.data_ptr(), 1, C.byref(d), L.BF16, st))
     want = base + q(F.conv_transpose2d(gy, w, None, 1, 1))
     assert rel_err(from_act(dxa, cin), want) < 6e-3
+
+
+@pytest.mark.parametrize("B,Ld", [(3, 256), (5, 128)])
+def test_fused_encoder_head_bf16(B, Ld):
+    """fc_mu|fc_var (1x1 conv, resnet.py:2245-2246) + reparameterise (resnet.py:2257-2259) in one launch against
+    torch fp32 on the same bf16-rounded operands and the same Philox noise; only the stored z is rounded to bf16."""
+    lib = L.lib()
+    cin, h = 128, 16
+    g = torch.Generator().manual_seed(11 + Ld)
+    q = lambda t: t.bfloat16().float()      # noqa: E731
+    w = q(torch.randn(2 * Ld, cin, 1, 1, generator=g) / cin ** 0.5)
+    bias = 0.1 * torch.randn(2 * Ld, generator=g)
+    x = q(torch.randn(B, cin, h, h, generator=g))
+    mulv = F.conv2d(x, w, bias)
+    d = L.ConvDesc(B, h, h, cin, 2 * Ld, 1, 1, 1, 0, 0)
+    assert lib.dvae_fc_reparam_supported(C.byref(d), Ld, L.BF16) == 1
+    assert lib.dvae_fc_reparam_supported(C.byref(d), Ld, L.F32) == 0
+    st = L.stream()
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    index = torch.tensor([7, 123456, 3, 49999, 0][:B], device="cuda", dtype=torch.int32)
+    seed, stream_id = 0x1234567890abcdef, 5
+    eps = torch.empty(B, h, h, Ld, device="cuda")
+    L.check(lib.dvae_philox_normal(eps.data_ptr(), index.data_ptr(), 0, B, h * h * Ld, seed, stream_id, st))
+    z_ref = eps.cpu().permute(0, 3, 1, 2) * torch.exp(0.5 * mulv[:, Ld:]) + mulv[:, :Ld]
+    xa = to_act(x, L.BF16)
+    z = torch.full((B, h, h, Ld), 7.0, device="cuda", dtype=torch.bfloat16)
+    bdev = bias.cuda()
+    L.check(lib.dvae_fc_reparam_fwd_philox(xa.data_ptr(), pk.data_ptr(), bdev.data_ptr(), z.data_ptr(), C.byref(d), Ld,
+                                           index.data_ptr(), 0, seed, stream_id, L.BF16, st))
+    assert rel_err(from_act(z, Ld), z_ref) < 6e-3
+    # contiguous image numbering (index NULL, first image given) draws the same stream
+    L.check(lib.dvae_philox_normal(eps.data_ptr(), None, 40000, B, h * h * Ld, seed, stream_id, st))
+    z_ref = eps.cpu().permute(0, 3, 1, 2) * torch.exp(0.5 * mulv[:, Ld:]) + mulv[:, :Ld]
+    L.check(lib.dvae_fc_reparam_fwd_philox(xa.data_ptr(), pk.data_ptr(), bdev.data_ptr(), z.data_ptr(), C.byref(d), Ld,
+                                           None, 40000, seed, stream_id, L.BF16, st))
+    assert rel_err(from_act(z, Ld), z_ref) < 6e-3
