@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
-                ("relu", C.c_int32), ("out_f32", C.c_int32), ("in_scale_shift", C.c_void_p), ("in_relu", C.c_int32)]
+                ("relu", C.c_int32), ("out_f32", C.c_int32), ("in_scale_shift", C.c_void_p), ("in_relu", C.c_int32),
+                ("out_stats", C.c_void_p)]
 
 
 _P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
@@ -55,6 +56,8 @@ _SIGS = {
     "dvae_emb_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dvae_philox_normal": (C.c_int, [_P, _P, _L, _I, _I, C.c_uint64, C.c_uint32, _P]),
     "dvae_reparam_kl_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dvae_conv_out_stats_floats": (_Z, [C.POINTER(ConvDesc), _I]),
+    "dvae_norm_stats_from_chunks": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "dvae_fc_reparam_supported": (C.c_int, [C.POINTER(ConvDesc), _I, _I]),
     "dvae_fc_reparam_fwd_philox": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P, _L, C.c_uint64, C.c_uint32, _I, _P]),
     "dvae_reparam_kl_fwd_philox": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _L, C.c_uint64, C.c_uint32, _I, _P]),

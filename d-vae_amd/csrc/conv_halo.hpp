@@ -39,6 +39,8 @@ struct HaloArgs {
     int relu, add_after_relu, out_f32;
     int lx, ly;              // log2 of the tile counts per image row / column (both powers of two)
     signed char dy[16], dx[16];
+    float* stats;            // optional [B][tiles per image * 8][2][NS]: sum and sum of squares of the stored bf16 output
+                             // over each wave's 32 pixels (for the normalisation that follows the conv), or null
     unsigned long long* stamps;   // profiling aid: [grid.x][64 tiles][8] cycle-counter samples of wave 0, or null
 };
 
@@ -169,6 +171,28 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // output statistics of this wave's 32 pixels, gathered while the patch is drained (coalesced layout: 8 channels per lane)
+    float ssum[8], ssq[8];
+    auto stats_add = [&](const u32x4& piece) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(&piece);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float f = (float)x[c]; ssum[c] += f; ssq[c] += f * f; }
+    };
+    auto stats_flush = [&](int tile) {                    // lanes holding the same 8 channels are VPS apart
+#pragma unroll
+        for (int o = VPS; o < 64; o <<= 1)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { ssum[c] += __shfl_xor(ssum[c], o, 64); ssq[c] += __shfl_xor(ssq[c], o, 64); }
+        if (sp == 0 && chunk_live) {
+            const int tpi = 1 << (a.lx + a.ly);
+            float* dst = a.stats + (((long)(tile >> (a.lx + a.ly)) * (tpi * 8) + (tile & (tpi - 1)) * 8 + wave) * 2) * a.NS +
+                         n0 + sc8 * 8;
+            f32x4 v0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, v1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
+            f32x4 q0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, q1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
+            *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
+            *reinterpret_cast<f32x4*>(dst + a.NS) = q0; *reinterpret_cast<f32x4*>(dst + a.NS + 4) = q1;
+        }
+    };
     // operand fragments of flattened step st = (tap, 16-channel slab): one pixel vector, TN weight vectors
     auto frag = [&](int st, bf16x8& pv, bf16x8 (&wv)[TN]) {
         const int t = st / KS, sl = st % KS;
@@ -199,8 +223,16 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         auto mem_op = [&](int q) {
             if (q <= NI) {
                 if (drain) {
-                    if (q > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(prev, q - 1)) = dreg;
+                    if (q == 0 && a.stats) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+                    }
+                    if (q > 0) {
+                        if (chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(prev, q - 1)) = dreg;
+                        if (a.stats) stats_add(dreg);
+                    }
                     if (q < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16);
+                    if (q == NI && a.stats) stats_flush(prev);
                 }
             } else if (q <= 2 * NI) {
                 const int i = q - NI - 1;
@@ -321,12 +353,17 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         HALO_STAMP(6);
     }
     // ---- the last tile's output is still parked in the patch ----
-    if (staged && it > 0 && chunk_live) {
+    if (staged && it > 0) {
         const int last = tile - gridDim.x;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-            *reinterpret_cast<u32x4*>(outb + out_off(last, i)) =
-                *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
+        for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const u32x4 piece = *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
+            if (chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(last, i)) = piece;
+            if (a.stats) stats_add(piece);
+        }
+        if (a.stats) stats_flush(last);
     }
 }
 #undef HALO_STAMP
@@ -367,7 +404,7 @@ static bool halo_applicable(const GemmPlan& P) { return halo_geom(P).TW != 0; }
 static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                  const float* shift, const void* res, int relu, int accumulate, int out_f32,
                                  hipStream_t st, const float* in_ss = nullptr, int in_relu = 0,
-                                 unsigned long long* stamps = nullptr) {
+                                 unsigned long long* stamps = nullptr, float* stats = nullptr) {
     const HaloGeom hg = halo_geom(P);
     if (!hg.TW) return false;
     const Phase& ph = P.ph[0];
@@ -376,7 +413,8 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     if (res && accumulate) return false;                  // one additive operand per launch
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift;
     a.add = res ? res : (accumulate ? out : nullptr); a.add_after_relu = accumulate ? 1 : 0;
-    a.in_ss = in_ss; a.in_relu = in_relu; a.stamps = stamps;
+    if (stats && out_f32) return false;                   // statistics ride on the bf16 drain
+    a.in_ss = in_ss; a.in_relu = in_relu; a.stamps = stamps; a.stats = stats;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.out_f32 = out_f32;
     a.lx = ilog2_exact(P.Wout / TW); a.ly = ilog2_exact(P.Hout / (256 / TW));

@@ -117,15 +117,18 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
     int rc = build_plan(*d, DVAE_OP_FWD, dtype, P);
     if (rc) return rc;
-    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
+    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr};
     if (ep) e = *ep;
+    if (e.out_stats && (dtype != DVAE_BF16 || e.out_f32 || !halo_applicable(P)))
+        DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused output statistics are not available for this shape/dtype "
+                               "(see dvae_conv_out_stats_floats)");
     if (e.in_scale_shift && (dtype != DVAE_BF16 || !halo_applicable(P)))
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation is not available for this shape/dtype "
                                "(see dvae_conv_supports_input_norm)");
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
     if (try_launch_halo_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), e.in_scale_shift,
-                             e.in_relu)) {
+                             e.in_relu, nullptr, e.out_stats)) {
         DVAE_CHECK_LAUNCH("conv_halo");
         return DVAE_OK;
     }
@@ -260,6 +263,25 @@ int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, fl
     DVAE_CHECK_LAUNCH("norm_stats");
     hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), partial, g.nchunk, C, gamma,
                        beta, (float*)nullptr, (float*)nullptr, save_mean, save_invstd, scale_shift, 0.f, eps);
+    DVAE_CHECK_LAUNCH("norm_finalize");
+    return DVAE_OK;
+}
+
+size_t dvae_conv_out_stats_floats(const dvae_conv_desc* d, int dtype) {
+    GemmPlan P;
+    if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P) || !halo_applicable(P)) return 0;
+    return (size_t)P.B * (P.Hout * P.Wout / 32) * 2 * P.NS;
+}
+
+int dvae_norm_stats_from_chunks(const float* chunks, int chunk_rows, const float* gamma, const float* beta, float* save_mean,
+                                float* save_invstd, float* scale_shift, int groups, int rows_per_group, int C, float eps,
+                                int dtype, void* st) {
+    int rc = norm_check(groups, rows_per_group, C, dtype);
+    if (rc) return rc;
+    if (!chunks || chunk_rows <= 0 || rows_per_group % chunk_rows) DVAE_FAIL(DVAE_EINVAL, "norm_stats_from_chunks: chunking");
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), chunks, rows_per_group / chunk_rows,
+                       C, gamma, beta, (float*)nullptr, (float*)nullptr, save_mean, save_invstd, scale_shift, 0.f, eps,
+                       chunk_rows);
     DVAE_CHECK_LAUNCH("norm_finalize");
     return DVAE_OK;
 }

@@ -110,11 +110,14 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* x, float* part
 // One workgroup per (8-channel tile, group): 32 lanes per channel merge the chunk triples (interleaved),
 // a 5-level tree combines them, then mean / invstd / scale / shift are written and (BatchNorm) the
 // running statistics are updated.
+// chunk_rows == 0: partial holds (count, mean, M2) triples [G][nchunk][3][C].  chunk_rows > 0: partial holds raw
+// (sum, sum of squares) pairs [G][nchunk][2][C] over chunk_rows values each, as a conv epilogue leaves them.
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial, int nchunk, int C,
                                                             const float* gamma, const float* beta,
                                                             float* running_mean, float* running_var,
                                                             float* save_mean, float* save_invstd,
-                                                            float* scale_shift, float momentum, float eps) {
+                                                            float* scale_shift, float momentum, float eps,
+                                                            int chunk_rows = 0) {
     __shared__ float sn[256], sm[256], sq[256];
     const int g = blockIdx.y;
     const int cl = threadIdx.x & 7, lane32 = threadIdx.x >> 3;
@@ -122,8 +125,14 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial
     float n = 0.f, m = 0.f, q = 0.f;
     if (c < C) {
         for (int ch = lane32; ch < nchunk; ch += 32) {
-            const float* p = partial + ((long)(g * nchunk + ch) * 3) * C + c;
-            chan_merge(n, m, q, p[0], p[C], p[2 * C]);
+            if (chunk_rows > 0) {
+                const float* p = partial + ((long)(g * nchunk + ch) * 2) * C + c;
+                const float cn = (float)chunk_rows, mean = p[0] / cn, m2 = p[C] - p[0] * mean;
+                chan_merge(n, m, q, cn, mean, m2 < 0.f ? 0.f : m2);
+            } else {
+                const float* p = partial + ((long)(g * nchunk + ch) * 3) * C + c;
+                chan_merge(n, m, q, p[0], p[C], p[2 * C]);
+            }
         }
     }
     sn[threadIdx.x] = n; sm[threadIdx.x] = m; sq[threadIdx.x] = q;

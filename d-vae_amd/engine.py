@@ -227,6 +227,9 @@ class DVAEEngine:
         self.packed_valid = False
         self._fuse_in = all(self.lib.dvae_conv_supports_input_norm(C.byref(self._desc(self.specs[n], 1)), dtype)
                             for n in ("decoder2.0", "decoder3.0"))
+        # the convs in front of the decoders' InstanceNorms can leave the statistics of their output behind
+        self._fuse_stats = all(self.lib.dvae_conv_out_stats_floats(C.byref(self._desc(self.specs[n], 1)), dtype) > 0
+                               for n in ("decoder1.1", "decoder2.0"))
         self._fuse_head = bool(self.lib.dvae_fc_reparam_supported(C.byref(self._desc(self.specs["fc"], 1)), self.Ld, dtype))
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
 
@@ -330,8 +333,9 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     # primitive launches
     # ------------------------------------------------------------------------------------------
-    def _conv(self, name, x, y, b, scale=None, shift=None, residual=None, relu=False, out_f32=False, in_ss=None, in_relu=False):
-        ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu))
+    def _conv(self, name, x, y, b, scale=None, shift=None, residual=None, relu=False, out_f32=False, in_ss=None, in_relu=False,
+              out_stats=None):
+        ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu), ptr(out_stats))
         pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
         if pr:
             pr[1][0].record()
@@ -536,10 +540,20 @@ class DVAEEngine:
         d1 = self.act(d + ".d1", S, 64)
         self._conv(d + "1.0", zin, d1, b, shift=self.param[d + "1.0.bias"])
         d2 = self.act(d + ".d2", S, 64)
-        self._conv(d + "1.1", d1, d2, b, shift=self.param[d + "1.1.bias"])
         d4 = self.act(d + ".d4", S, 32)
         d6 = self.act(d + ".d6", S, 3, f32=True)       # rec_pre / perturbation stay fp32 on every path
         fuse = (not train) and self._fuse_in
+        if fuse and self._fuse_stats:
+            # statistics ride on the producing conv's store, normalisation on the consuming conv's load
+            ch1 = self.buf(d + ".in1.chunks", (self.B, S * S // 32, 2, d2.shape[-1]), torch.float32)
+            ch2 = self.buf(d + ".in2.chunks", (self.B, S * S // 32, 2, d4.shape[-1]), torch.float32)
+            self._conv(d + "1.1", d1, d2, b, shift=self.param[d + "1.1.bias"], out_stats=ch1)
+            ss1 = self._in_stats_chunks(d + ".in1", ch1, b, 64)
+            self._conv(d + "2.0", d2, d4, b, shift=self.param[d + "2.0.bias"], in_ss=ss1, in_relu=True, out_stats=ch2)
+            ss2 = self._in_stats_chunks(d + ".in2", ch2, b, 32)
+            self._conv(d + "3.0", d4, d6, b, shift=self.param[d + "3.0.bias"], out_f32=True, in_ss=ss2, in_relu=True)
+            return d6
+        self._conv(d + "1.1", d1, d2, b, shift=self.param[d + "1.1.bias"])
         if fuse:
             ss1 = self._in_stats(d + ".in1", d2, b, 64)
             self._conv(d + "2.0", d2, d4, b, shift=self.param[d + "2.0.bias"], in_ss=ss1, in_relu=True)
@@ -560,6 +574,15 @@ class DVAEEngine:
         ss = self.buf(tag + ".ss", (self.B, 2, c), torch.float32)
         check(self.lib.dvae_norm_fwd_stats(ptr(x), None, None, ptr(mean), ptr(invstd), ptr(ss), ptr(self.norm_ws),
                                            self.norm_ws.numel() * 4, b, self.S * self.S, c, IN_EPS, self.dtype, L.stream()))
+        return ss
+
+    def _in_stats_chunks(self, tag, chunks, b, c):
+        """InstanceNorm statistics from the (sum, sum of squares) chunks the producing conv left behind."""
+        mean = self.buf(tag + ".mean", (self.B, c), torch.float32)
+        invstd = self.buf(tag + ".invstd", (self.B, c), torch.float32)
+        ss = self.buf(tag + ".ss", (self.B, 2, c), torch.float32)
+        check(self.lib.dvae_norm_stats_from_chunks(ptr(chunks), 32, None, None, ptr(mean), ptr(invstd), ptr(ss), b,
+                                                   self.S * self.S, c, IN_EPS, self.dtype, L.stream()))
         return ss
 
     # ------------------------------------------------------------------------------------------

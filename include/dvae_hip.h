@@ -65,6 +65,11 @@ typedef struct dvae_epilogue {
      * dvae_conv_supports_input_norm() says so; NULL = off. */
     const float* in_scale_shift;
     int32_t in_relu;
+    /* Optional fused statistics of the stored output (the InstanceNorm2d that follows the conv, resnet.py:2030-2046):
+     * per image, per 32-pixel chunk and per channel the sum and the sum of squares, fp32
+     * [B][H*W/32][2][act channels]; dvae_norm_stats_from_chunks turns them into mean / invstd / scale-shift.
+     * dvae_conv_out_stats_floats() gives the size, 0 where the conv cannot produce them; NULL = off. */
+    float* out_stats;
 } dvae_epilogue;
 
 const char* dvae_version(void);
@@ -120,6 +125,12 @@ int dvae_bn_fwd_eval(const void* x, const void* residual, void* y,
                      float* scale_shift /* [2][C] scratch */, int rows, int C, int relu, float eps,
                      int dtype, void* stream);
 /* eval-mode BatchNorm folded to a per-channel scale/shift for dvae_conv_fwd's epilogue */
+/* Statistics of a normalisation group from the (sum, sum of squares) chunks a conv epilogue left in `chunks`
+ * ([groups][rows_per_group / chunk_rows][2][C], see dvae_epilogue.out_stats): same outputs as dvae_norm_fwd_stats. */
+size_t dvae_conv_out_stats_floats(const dvae_conv_desc* d, int dtype);
+int dvae_norm_stats_from_chunks(const float* chunks, int chunk_rows, const float* gamma, const float* beta,
+                                float* save_mean, float* save_invstd, float* scale_shift, int groups,
+                                int rows_per_group, int C, float eps, int dtype, void* stream);
 int dvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float* scale, float* shift, int C, float eps, void* stream);
 int dvae_norm_bwd(const void* dy, const void* y, const void* x,

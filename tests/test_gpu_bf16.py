@@ -232,3 +232,45 @@ def test_fused_encoder_head_bf16(B, Ld):
     L.check(lib.dvae_fc_reparam_fwd_philox(xa.data_ptr(), pk.data_ptr(), bdev.data_ptr(), z.data_ptr(), C.byref(d), Ld,
                                            None, 40000, seed, stream_id, L.BF16, st))
     assert rel_err(from_act(z, Ld), z_ref) < 6e-3
+
+
+@pytest.mark.parametrize("cin,cout,hin,tr", [(64, 64, 32, True), (64, 32, 32, True), (64, 64, 16, False)])
+def test_conv_output_statistics_bf16(cin, cout, hin, tr):
+    """InstanceNorm2d statistics (resnet.py:2030-2046) gathered by the producing conv's store against the
+    stand-alone statistics kernel on the stored tensor: same values up to fp32 summation order."""
+    lib = L.lib()
+    B = 5
+    g = torch.Generator().manual_seed(3 + cout + hin)
+    sp = ConvSpec("t", cin, cout, 3, 1, 1, tr, hin, True)
+    w = torch.randn(sp.wshape, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g).cuda()
+    x = torch.randn(B, cin, hin, hin, generator=g) + 0.5
+    d = L.ConvDesc(B, hin, hin, cin, cout, 3, 3, 1, 1, int(tr))
+    st = L.stream()
+    n = lib.dvae_conv_out_stats_floats(C.byref(d), L.BF16)
+    cs = L.act_channels(cout, L.BF16)
+    assert n == B * (hin * hin // 32) * 2 * cs
+    assert lib.dvae_conv_out_stats_floats(C.byref(d), L.F32) == 0
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    xa = to_act(x, L.BF16)
+    ya = torch.empty(B, hin, hin, cs, device="cuda", dtype=torch.bfloat16)
+    chunks = torch.full((n,), float("nan"), device="cuda")
+    ep = L.Epilogue(None, L.ptr(bias), None, 0, 0, None, 0, chunks.data_ptr())
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), ya.data_ptr(), C.byref(d), L.BF16, st))
+    out = {}
+    for tag in ("fused", "alone"):
+        out[tag] = [torch.empty(B, cs, device="cuda"), torch.empty(B, cs, device="cuda"), torch.empty(B, 2, cs, device="cuda")]
+    m, i, s = out["fused"]
+    L.check(lib.dvae_norm_stats_from_chunks(chunks.data_ptr(), 32, None, None, m.data_ptr(), i.data_ptr(), s.data_ptr(), B,
+                                            hin * hin, cs, 1e-5, L.BF16, st))
+    m, i, s = out["alone"]
+    ws = torch.empty(lib.dvae_norm_workspace_bytes(B, hin * hin, cs) // 4 + 4, device="cuda")
+    L.check(lib.dvae_norm_fwd_stats(ya.data_ptr(), None, None, m.data_ptr(), i.data_ptr(), s.data_ptr(), ws.data_ptr(),
+                                    ws.numel() * 4, B, hin * hin, cs, 1e-5, L.BF16, st))
+    for a_, b_ in zip(out["fused"], out["alone"]):
+        assert torch.isfinite(a_[..., :cout]).all()
+        assert rel_err(a_[..., :cout], b_[..., :cout]) < 2e-5
+    # and against torch on the stored values
+    y = from_act(ya, cout).float()
+    assert rel_err(out["fused"][0][:, :cout].cpu(), y.mean(dim=(2, 3))) < 2e-5
