@@ -249,17 +249,19 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         {
-            // fully unrolled over the 9 taps x KS slabs; the next step's fragments are read while this step's MFMAs issue
-            bf16x8 pv[2], wv[2][TN];
-            frag(0, pv[0], wv[0]);
+            // fully unrolled over the 9 taps x KS slabs; fragments are read PF steps ahead of the MFMAs that use them
+            constexpr int PF = 1;
+            bf16x8 pv[PF + 1], wv[PF + 1][TN];
+#pragma unroll
+            for (int st = 0; st < PF; ++st) frag(st, pv[st], wv[st]);
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
-                if (st + 1 < NSTEP) frag(st + 1, pv[(st + 1) & 1], wv[(st + 1) & 1]);
+                if (st + PF < NSTEP) frag(st + PF, pv[(st + PF) % (PF + 1)], wv[(st + PF) % (PF + 1)]);
                 if (st % OPSTRIDE == 0 && st / OPSTRIDE < NOPS) mem_op(st / OPSTRIDE);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     // D[i = out channel][j = pixel]: each lane ends up with 4 consecutive channels per register quad
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[st & 1][j], pv[st & 1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[st % (PF + 1)][j], pv[st % (PF + 1)], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);         // keep the memory operations where they were placed
             }
         }

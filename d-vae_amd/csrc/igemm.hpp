@@ -619,8 +619,10 @@ static int launch_igemm_zf(const GemmPlan& P, const void* in, const void* wp, co
     const long M = (long)P.B * P.Hout * P.Wout;
     if (M > 0x7fffffffL / 2 || M * P.CgS > 0x7fffffffL || M * L > 0x7fffffffL) DVAE_FAIL(DVAE_EINVAL, "tensor exceeds 2^31 elements");
     if (M == 0) return DVAE_OK;
-    dim3 grid((unsigned)((M + 127) / 128), P.N / 256, 1), block(256);
-    hipLaunchKernelGGL((igemm_kernel<bf16, 2, 4, 2, 2, true>), grid, block, 0, st, a);
+    // 128 x 128 tiles (64 latent channels per workgroup): 2 workgroups per CU, so one's Philox epilogue overlaps the
+    // other's loads and MFMAs; the 128 x 256 tile needs > 256 registers and runs alone
+    dim3 grid((unsigned)((M + 127) / 128), P.N / 128, 1), block(256);
+    hipLaunchKernelGGL((igemm_kernel<bf16, 2, 2, 2, 2, true>), grid, block, 0, st, a);
     DVAE_CHECK_LAUNCH("igemm_zf");
     return DVAE_OK;
 }
