@@ -51,6 +51,12 @@ struct HaloArgs {
             a.stamps[((long)blockIdx.x * 64 + it) * 8 + (i)] = __builtin_readcyclecounter();        \
     } while (0)
 
+// value of `x` in the lane selected by a DPP control word (row-local permutations; all lanes active)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
 template <int CIN, int NT, int TW>
 __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     constexpr int TH = 256 / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
@@ -178,17 +184,28 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) { const float f = (float)x[c]; ssum[c] += f; ssq[c] += f * f; }
     };
-    auto stats_flush = [&](int tile) {                    // lanes holding the same 8 channels are VPS apart
+    auto stats_flush = [&](int tile) {
+        // Sum over the lanes that hold the same 8 channels (VPS apart): DPP butterflies inside a 16-lane row (no LDS
+        // queue traffic), cross-lane shuffles across rows.
+        float v[16];
 #pragma unroll
-        for (int o = VPS; o < 64; o <<= 1)
+        for (int c = 0; c < 8; ++c) { v[c] = ssum[c]; v[8 + c] = ssq[c]; }
+        if (VPS == 4) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { ssum[c] += __shfl_xor(ssum[c], o, 64); ssq[c] += __shfl_xor(ssq[c], o, 64); }
+            for (int i = 0; i < 16; ++i) v[i] += dpp_f<0x1B>(dpp_f<0x141>(v[i]));      // lane ^ 4: half-row mirror, then quad reverse
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += dpp_f<0x128>(v[i]);                        // lane ^ 8: rotate the row by 8
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 16, 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 32, 64);
         if (sp == 0 && chunk_live) {
             const int tpi = 1 << (a.lx + a.ly);
             float* dst = a.stats + (((long)(tile >> (a.lx + a.ly)) * (tpi * 8) + (tile & (tpi - 1)) * 8 + wave) * 2) * a.NS +
                          n0 + sc8 * 8;
-            f32x4 v0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, v1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
-            f32x4 q0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, q1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
+            f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+            f32x4 q0 = {v[8], v[9], v[10], v[11]}, q1 = {v[12], v[13], v[14], v[15]};
             *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
             *reinterpret_cast<f32x4*>(dst + a.NS) = q0; *reinterpret_cast<f32x4*>(dst + a.NS + 4) = q1;
         }

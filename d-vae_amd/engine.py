@@ -424,14 +424,16 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
-    def forward(self, x0, y, eps, b, train: bool):
+    def forward(self, x0, y, eps, b, train: bool, need_rec: bool = True):
         """x0: input act [B,S,S,4]; y: int64 [b]; eps: fp32 act [B,h,h,L].  Leaves rec_pre / p (and
-        every intermediate needed by backward) in the engine's buffers and returns them."""
+        every intermediate needed by backward) in the engine's buffers and returns them.
+        ``need_rec=False`` (inference only) leaves the reconstruction branch out and returns (None, p): for callers
+        that read nothing but the perturbation of this pass (main_vae_disentangle.py:61-62)."""
         stem_out = self.stem(x0, b, train)
         _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train)
         if isinstance(eps, PhiloxEps):
             eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
-        rec_pre = self._decoder("decoder", z, b, train)
+        rec_pre = self._decoder("decoder", z, b, train) if (train or need_rec) else None
         p = self.perturb(stem_out, z, y, b, train)
         self._last = dict(b=b, x0=x0, y=y, eps=eps, stem_out=stem_out, train=train)
         return rec_pre, p
@@ -748,17 +750,20 @@ class DVAEEngine:
             allreduce(self.G)
         self.adam_step()
 
-    def purify_batch(self, data_u8, out_u8, noise_out, labels, first, b, stage, eps_nchw=None, global_first=None):
+    def purify_batch(self, data_u8, out_u8, noise_out, labels, first, b, stage, eps_nchw=None, global_first=None,
+                     skip_unread=False):
         """Purify images [first, first+b) of the resident uint8 set (main_vae_disentangle.py:59-69).
         Writes uint8 HWC into out_u8[first:first+b] and the (last) perturbation, NCHW fp32, into
         noise_out[first:first+b].  ``eps_nchw``: optional (pass0, pass1) injected noise; otherwise the
-        noise is Philox keyed by the global image index ``global_first + i`` (shard-invariant)."""
+        noise is Philox keyed by the global image index ``global_first + i`` (shard-invariant).
+        ``skip_unread``: the first pass computes only what :61-62 reads of it (the perturbation); the reference also
+        runs that pass's reconstruction decoder and drops the result.  Outputs are bit-identical either way."""
         S = self.S
         gf = first if global_first is None else global_first
         y = labels[first:first + b]
         x0 = self.input_from_u8(data_u8, first, b)
         eps = self.eps_from_nchw(eps_nchw[0]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=1)
-        _, p = self.forward(x0, y, eps, b, False)
+        _, p = self.forward(x0, y, eps, b, False, need_rec=not skip_unread)
         if stage == 0:
             check(self.lib.dvae_purify_quant(ptr(x0), ptr(p), 0, None, ptr(out_u8), int(first), b, S * S, self.dtype, L.stream()))
         else:

@@ -163,6 +163,12 @@ def test_purification_bf16_close_to_fp32_and_shard_invariant(stage):
     for lo in range(0, N, 100):
         e16.purify_batch(data, out2, noise2, labels, lo, min(100, N - lo), stage)
     assert torch.equal(out2, outs["bf16"][0]) and torch.equal(noise2, outs["bf16"][1])
+    # leaving out what main_vae_disentangle.py:61-62 never reads of the first pass changes no output bit
+    out3 = torch.zeros_like(data)
+    noise3 = torch.zeros(N, 3, 32, 32, device="cuda")
+    for lo in range(0, N, 256):
+        e16.purify_batch(data, out3, noise3, labels, lo, 256, stage, skip_unread=True)
+    assert torch.equal(out3, outs["bf16"][0]) and torch.equal(noise3, outs["bf16"][1])
 
 
 def test_conv_bf16_fused_epilogue_and_accumulate():
