@@ -132,6 +132,8 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
         DVAE_CHECK_LAUNCH("conv_halo");
         return DVAE_OK;
     }
+    if (e.in_scale_shift || e.out_stats)                  // the gather GEMM has neither: never drop them silently
+        DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation / output statistics unavailable for this launch");
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
 }
 
