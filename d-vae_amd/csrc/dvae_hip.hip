@@ -281,9 +281,15 @@ int dvae_norm_stats_from_chunks(const float* chunks, int chunk_rows, const float
     int rc = norm_check(groups, rows_per_group, C, dtype);
     if (rc) return rc;
     if (!chunks || chunk_rows <= 0 || rows_per_group % chunk_rows) DVAE_FAIL(DVAE_EINVAL, "norm_stats_from_chunks: chunking");
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), chunks, rows_per_group / chunk_rows,
-                       C, gamma, beta, (float*)nullptr, (float*)nullptr, save_mean, save_invstd, scale_shift, 0.f, eps,
-                       chunk_rows);
+    const int nchunk = rows_per_group / chunk_rows;
+    if (nchunk <= 256) {
+        const int CB = C < 256 ? C : 256;                 // C is a power of two (norm_check)
+        hipLaunchKernelGGL(norm_finalize_chunks_kernel, dim3(C / CB, groups), dim3(256), 0, S(st), chunks, nchunk, C, CB,
+                           chunk_rows, gamma, beta, save_mean, save_invstd, scale_shift, eps);
+    } else {
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, S(st), chunks, nchunk, C, gamma, beta,
+                           (float*)nullptr, (float*)nullptr, save_mean, save_invstd, scale_shift, 0.f, eps, chunk_rows);
+    }
     DVAE_CHECK_LAUNCH("norm_finalize");
     return DVAE_OK;
 }
@@ -471,15 +477,16 @@ int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out, 
     const int CS = act_c(3, dtype);
     const int g = grid_for((long)B * HW);
     const float* bf = (const float*)b;
+    const int sig = a_is_f32 == 2 ? 1 : 0;               // a is the decoder's pre-activation: sigmoid first
     if (dtype == DVAE_F32)
         hipLaunchKernelGGL((purify_quant_kernel<float, float>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4, bf, CS,
-                           (float*)v_out, u8, (long)first, B, HW);
+                           (float*)v_out, u8, (long)first, B, HW, sig);
     else if (dtype == DVAE_BF16 && a_is_f32)
         hipLaunchKernelGGL((purify_quant_kernel<float, bf16>), dim3(g), dim3(256), 0, S(st), (const float*)a, 4, bf, CS,
-                           (bf16*)v_out, u8, (long)first, B, HW);
+                           (bf16*)v_out, u8, (long)first, B, HW, sig);
     else if (dtype == DVAE_BF16)
         hipLaunchKernelGGL((purify_quant_kernel<bf16, bf16>), dim3(g), dim3(256), 0, S(st), (const bf16*)a, CS, bf, CS,
-                           (bf16*)v_out, u8, (long)first, B, HW);
+                           (bf16*)v_out, u8, (long)first, B, HW, 0);
     else
         DVAE_FAIL(DVAE_EDTYPE, "unknown dtype %d", dtype);
     DVAE_CHECK_LAUNCH("purify_quant");

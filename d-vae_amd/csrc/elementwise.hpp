@@ -305,14 +305,20 @@ __global__ __launch_bounds__(256) void recon_loss_bwd_kernel(const float* rec, c
 // ------------------------------------------------------------------------------------------------
 // purification epilogue: v = clamp(a - b, 0, 1); u8 = trunc(255 * v) (fp32 product, as numpy does)
 // ------------------------------------------------------------------------------------------------
-// a: the image (act dtype) or rec (fp32 [.,4]); b: the perturbation, fp32 [.,4], or NULL.
+// a: the image (act dtype), rec (fp32 [.,4]) or, with `sigmoid`, the decoder's pre-activation (fp32 [.,4]);
+// b: the perturbation, fp32 [.,4], or NULL.
 template <typename TA, typename T>
-__global__ void purify_quant_kernel(const TA* a, int CSA, const float* b, int CS, T* vout, uint8_t* u8, long first, int B, int HW) {
+__global__ void purify_quant_kernel(const TA* a, int CSA, const float* b, int CS, T* vout, uint8_t* u8, long first, int B, int HW,
+                                    int sigmoid) {
     const long total = (long)B * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float av[4], bv[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
         Act<TA>::load4(a + i * CSA, av);
         if (b) Act<float>::load4(b + i * 4, bv);
+        if (sigmoid) {                                   // same expression as recon_loss_fwd_kernel: identical bits
+#pragma unroll
+            for (int c = 0; c < 3; ++c) av[c] = 1.f / (1.f + expf(-av[c]));
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = fminf(fmaxf(av[c] - bv[c], 0.f), 1.f);
         v[3] = 0.f;

@@ -182,6 +182,49 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial
     }
 }
 
+// Finalize for the (sum, sum of squares) chunks a conv epilogue leaves, [G][nchunk][2][C] over chunk_rows values each,
+// when there are few chunks per group (InstanceNorm: H*W/32 of them): one workgroup per group and block of CB <= 256
+// channels, 256/CB lanes per channel walk the chunks with their loads issued together, one LDS hand-over combines them.
+__global__ __launch_bounds__(256) void norm_finalize_chunks_kernel(const float* partial, int nchunk, int C, int CB,
+                                                                   int chunk_rows, const float* gamma, const float* beta,
+                                                                   float* save_mean, float* save_invstd,
+                                                                   float* scale_shift, float eps) {
+    __shared__ float sn[256], sm[256], sq[256];
+    const int g = blockIdx.y;
+    const int lpc = 256 / CB, cl = threadIdx.x % CB, q = threadIdx.x / CB;
+    const int c = blockIdx.x * CB + cl;
+    const float cn = (float)chunk_rows;
+    float n = 0.f, m = 0.f, qq = 0.f;
+    for (int ch0 = q; ch0 < nchunk; ch0 += 8 * lpc) {
+        float ps[8], pq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ch = ch0 + u * lpc;
+            const float* p = partial + ((long)(g * nchunk + (ch < nchunk ? ch : ch0)) * 2) * C + c;
+            ps[u] = p[0]; pq[u] = p[C];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ch0 + u * lpc >= nchunk) break;
+            const float mean = ps[u] / cn, m2 = pq[u] - ps[u] * mean;
+            chan_merge(n, m, qq, cn, mean, m2 < 0.f ? 0.f : m2);
+        }
+    }
+    sn[threadIdx.x] = n; sm[threadIdx.x] = m; sq[threadIdx.x] = qq;
+    __syncthreads();
+    if (q == 0) {
+        for (int o = 1; o < lpc; ++o) chan_merge(n, m, qq, sn[o * CB + cl], sm[o * CB + cl], sq[o * CB + cl]);
+        const float var = qq / n;
+        const float invstd = 1.0f / sqrtf(var + eps);
+        save_mean[(long)g * C + c] = m;
+        save_invstd[(long)g * C + c] = invstd;
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        const float sc = ga * invstd;
+        scale_shift[((long)g * 2) * C + c] = sc;
+        scale_shift[((long)g * 2 + 1) * C + c] = be - m * sc;
+    }
+}
+
 __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                     float* scale, float* shift, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -771,10 +771,7 @@ class DVAEEngine:
             check(self.lib.dvae_purify_quant(ptr(x0), ptr(p), 0, ptr(x1), None, 0, b, S * S, self.dtype, L.stream()))
             eps = self.eps_from_nchw(eps_nchw[1]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=2)
             rec_pre, p = self.forward(x1, y, eps, b, False)
-            rec = self.buf("rec", (self.B, S, S, 4), torch.float32)
-            # sigmoid via the loss kernel's forward half (the sums are ignored here)
-            check(self.lib.dvae_recon_loss_fwd(ptr(rec_pre), ptr(p), ptr(x1), ptr(rec), ptr(self.recon_partial), b * S * S,
-                                               self.dtype, L.stream()))
-            check(self.lib.dvae_purify_quant(ptr(rec), None, 1, None, ptr(out_u8), int(first), b, S * S, self.dtype, L.stream()))
+            # rec = sigmoid(rec_pre), clamp and quantise in one launch
+            check(self.lib.dvae_purify_quant(ptr(rec_pre), None, 2, None, ptr(out_u8), int(first), b, S * S, self.dtype, L.stream()))
         if noise_out is not None:
             self.to_nchw(p, b, 3, S, out=noise_out[first:first + b])

@@ -203,8 +203,9 @@ int dvae_recon_loss_bwd(const float* rec, const float* p, const void* x, const f
                         void* d_rec_pre, void* d_p, int npix, int dtype, void* stream);
 
 /* ---- purification epilogue (main_vae_disentangle.py:62, :65, :67) ----------------------------
- * v = clamp(a - b, 0, 1); a is the image (act tensor) or, with a_is_f32, rec (fp32 [npix][4]); b is the
- * perturbation (fp32 [npix][4]) or NULL; u8 = trunc(255 * v) stored HWC at image `first`+i; v itself is
+ * v = clamp(a - b, 0, 1); a is the image (act tensor), or with a_is_f32 == 1 rec (fp32 [npix][4]), or with
+ * a_is_f32 == 2 the decoder's pre-activation (fp32 [npix][4]; rec = sigmoid(a) is formed here, resnet.py:2028);
+ * b is the perturbation (fp32 [npix][4]) or NULL; u8 = trunc(255 * v) stored HWC at image `first`+i; v itself is
  * optionally stored as the next pass's input (act tensor). */
 int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out /* or NULL */,
                       uint8_t* out_u8_nhwc /* or NULL */, int64_t first, int B, int HW, int dtype, void* stream);
