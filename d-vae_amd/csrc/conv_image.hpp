@@ -1,0 +1,294 @@
+// bf16 transposed-gather convolution with a whole (small) input image resident in LDS.
+//
+// ConvTranspose2d(k4, s2, p1) forward -- and the input-gradient of a stride-2 Conv2d -- decompose into output-parity
+// phases: phase (py, px) is a 2x2-tap unit-stride convolution of the 16x16 input that writes every other output
+// pixel.  All phases read the same input, so one workgroup keeps the whole 18x18 halo of one image (128 channels) in
+// LDS for all of them, and streams the weights through LDS one (phase, tap) slab of 64 x 128 at a time, double-buffered:
+// slabs are fetched into a register ring three steps ahead (an L2 round trip under load is longer than one step's
+// MFMAs) and written to the idle LDS buffer one step ahead, before the step's barrier.  The gather GEMM of igemm.hpp re-fetches the input rows once per tap and per phase through L2 and
+// synchronises twice per 64-deep K slab; here an image's input is read from HBM once and a barrier buys 16 MFMAs per wave.
+//
+// Persistent workgroups (one per CU, 8 waves) walk the images.  A wave owns 32 pixels of the 16x16 phase grid and all
+// 64 output channels; the MFMA is issued as D[channel][pixel] = W * X^T, the finished phase is parked as bf16 in the
+// wave's private LDS patch and drained to HBM as whole 128-byte pixel rows from inside the next step's MFMA loop, where
+// the next image's halo is prefetched into registers as well.
+#pragma once
+#include <type_traits>
+
+#include "igemm.hpp"
+
+namespace dvae {
+
+struct ImageConvArgs {
+    const void* in;
+    const void* wp;
+    void* out;
+    const float* shift;      // per-output-channel bias or NULL
+    int relu;
+    int B, Hout, Wout, N, NS, Ktot;
+    int nslab, DS;           // (phase, tap) slabs per image; output step of a phase grid step
+    // per slab: halo offset of the tap (pixels), first K column in the packed rows, phase << 1 | last tap of its phase;
+    // per phase: output offset.  Copied to LDS at kernel start: indexing kernel arguments with a run-time index costs a
+    // vector load and a wait on every outstanding load each time
+    int slab_toff[16], slab_k0[16], slab_phase[16];
+    int phase_d0y[4], phase_d0x[4];
+};
+
+// NSLAB (phase, tap) slabs per image; bit q of LASTMASK: slab q is the last tap of its phase.  Both are compile-time so
+// that an image is one straight-line block: with the register ring, the halo prefetch and the drain stores all in
+// flight at once, the wait counts the compiler derives are exact only if no branch separates a load from its use.
+template <int CIN, int NT, int NSLAB, unsigned LASTMASK>
+__global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArgs a) {
+    constexpr int S = 16, HWD = S + 2, HP = HWD * HWD;    // input image side; halo side; halo pixels
+    constexpr int RS = CIN * 2 + 16;                      // bytes per staged pixel / weight row (16-byte pad spreads banks)
+    constexpr int VPP = CIN * 2 / 16;                     // 16-byte vectors per pixel / weight row
+    constexpr int HALO_BYTES = HP * RS, WBUF = NT * RS;
+    constexpr int TN = NT / 32, KS = CIN / 16;
+    constexpr int HV = (HP * VPP + 511) / 512;            // halo vectors per thread
+    constexpr int WV = NT * VPP / 512;                    // weight-slab vectors per thread
+    constexpr int SRS = NT * 2 + 16, VPS = NT / 8, PPI = 64 / VPS, NI = 32 / PPI;
+    constexpr int RING = (NSLAB % 4 == 0) ? 4 : 3;        // slabs in flight in registers; divides NSLAB: static slots
+    static_assert(NSLAB % RING == 0, "ring slots must be static per slab");
+    static_assert(NT * VPP % 512 == 0 && NI + 1 <= KS && HV <= 2 * KS && NSLAB >= 2, "slab split / drain and prefetch slots");
+    static_assert((LASTMASK >> (NSLAB - 1)) & 1u, "the last slab of an image ends a phase");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;                                     // [HP][RS]
+    unsigned char* wbuf = smem + HALO_BYTES;                        // [2][NT][RS]
+    float* ssl = reinterpret_cast<float*>(smem + HALO_BYTES + 2 * WBUF);   // shift[NT]
+    int* tab = reinterpret_cast<int*>(smem + HALO_BYTES + 2 * WBUF + NT * 4 + 8 * 32 * SRS);   // [16][4] slabs, then [4][2] phases
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    unsigned char* stg = smem + HALO_BYTES + 2 * WBUF + NT * 4 + wave * (32 * SRS);
+
+    const bf16* in = reinterpret_cast<const bf16*>(a.in);
+    const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
+    bf16* outb = reinterpret_cast<bf16*>(a.out);
+    if (tid < NT) ssl[tid] = (tid < a.N && a.shift) ? a.shift[tid] : 0.f;
+    if (tid < 16) { tab[tid * 4 + 0] = a.slab_toff[tid] * RS; tab[tid * 4 + 1] = a.slab_k0[tid]; }
+    if (tid < 4) { tab[64 + tid * 2] = a.phase_d0y[tid]; tab[64 + tid * 2 + 1] = a.phase_d0x[tid]; }
+    __syncthreads();
+
+    // ---- halo: HV vectors per thread, border pixels (outside the image) are zeros ----
+    u32x4 hreg[HV];
+    auto halo_pos = [&](int k, int& hp, int& cv) { const int v = tid + 512 * k; hp = v / VPP; cv = v % VPP; };
+    auto load_halo_vec = [&](int b, int k) {
+        int hp, cv;
+        halo_pos(k, hp, cv);
+        const int iy = hp / HWD - 1, ix = hp % HWD - 1;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
+        // border / tail vectors read pixel 0 of the image and are zeroed on the way to LDS: no branch around the load
+        const int py = ok ? iy : 0, px = ok ? ix : 0;
+        hreg[k] = *reinterpret_cast<const u32x4*>(in + ((long)(b * S + py) * S + px) * CIN + cv * 8);
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            int hp, cv;
+            halo_pos(k, hp, cv);
+            if (hp >= HP) continue;
+            const int iy = hp / HWD - 1, ix = hp % HWD - 1;
+            const bool ok = (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(halo + hp * RS + cv * 16) = ok ? hreg[k] : z;
+        }
+    };
+    // ---- weight slab q = (phase, tap): NT rows of CIN, WV vectors per thread, ring slot q % RING ----
+    u32x4 wreg[RING][WV];
+    auto load_slab = [&](int slot, int q) {                // slot, q: compile-time at every call site
+        const int k0 = __builtin_amdgcn_readfirstlane(tab[q * 4 + 1]);
+#pragma unroll
+        for (int k = 0; k < WV; ++k) {
+            const int v = tid + 512 * k, n = v / VPP, cv = v % VPP;
+            wreg[slot][k] = *reinterpret_cast<const u32x4*>(wp + (long)n * a.Ktot + k0 + cv * 8);
+        }
+    };
+    auto store_slab = [&](int slot, int buf) {
+#pragma unroll
+        for (int k = 0; k < WV; ++k) {
+            const int v = tid + 512 * k, n = v / VPP, cv = v % VPP;
+            *reinterpret_cast<u32x4*>(wbuf + buf * WBUF + n * RS + cv * 16) = wreg[slot][k];
+        }
+    };
+
+    // wave w owns phase-grid pixels [32w, 32w + 32): rows 2w, 2w + 1; lane r is pixel 32w + r
+    const int gy = 2 * wave + (r >> 4), gx = r & 15;
+    const unsigned char* hrow = halo + ((gy + 1) * HWD + gx + 1) * RS + 16 * h;
+    const unsigned char* wrow = wbuf + r * RS + 16 * h;
+    const int sp = lane / VPS, sc8 = lane % VPS;           // coalesced side: lane = (pixel sp of a PPI group, 8-channel chunk sc8)
+    const bool chunk_live = sc8 * 8 < a.NS;
+    auto out_off = [&](int b, int p, int i) -> long {      // this lane's 16-byte piece i of phase p's output rows
+        const int q = i * PPI + sp;                        // pixel of the wave's 32
+        const int oy = (2 * wave + (q >> 4)) * a.DS + tab[64 + p * 2], ox = (q & 15) * a.DS + tab[64 + p * 2 + 1];
+        return ((long)(b * a.Hout + oy) * a.Wout + ox) * a.NS + sc8 * 8;
+    };
+    auto wave_lds_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto phase_of = [](int q) { int p = 0; for (int i = 0; i < q; ++i) p += (LASTMASK >> i) & 1u; return p; };
+
+    const int G = gridDim.x;
+    int b = blockIdx.x;
+    if (b >= a.B) return;                                  // whole workgroup: grid <= B, never taken
+#pragma unroll
+    for (int k = 0; k < HV; ++k) load_halo_vec(b, k);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) load_slab(i, i % NSLAB);
+    store_slab(0, 0);
+    bool have_prev = false;                                // an earlier image's last phase is parked in the patch
+    int pb = b;
+    int par = 0;                                           // LDS buffer of an image's slab 0 (alternates when NSLAB is odd)
+    u32x4 dreg;
+    f32x16 acc[TN];
+    for (; b < a.B; b += G) {
+        store_halo();
+        __syncthreads();                                   // halo (and, first time, slab 0 and ssl) visible
+        const int nb = b + G < a.B ? b + G : b;            // next image, or this one again: the prefetch is unconditional
+#pragma unroll
+        for (int q = 0; q < NSLAB; ++q) {
+            const int buf = (q & 1) ^ par;
+            const bool first_tap = q == 0 || ((LASTMASK >> (q - 1)) & 1u);
+            const bool last_tap = (LASTMASK >> q) & 1u;
+            if (first_tap) {                               // a new phase: the accumulators start from the bias
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + j * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[j][4 * g + k] = sh[k];
+                    }
+            }
+            // this slab's ring slot was emptied into LDS a step ago: refill it with the slab RING steps ahead
+            load_slab(q % RING, (q + RING) % NSLAB);
+            const int toff = __builtin_amdgcn_readfirstlane(tab[q * 4]);
+            const unsigned char* hp_ = hrow + toff;
+            const unsigned char* wp_ = wrow + buf * WBUF;
+            // what is parked in the patch: the previous slab's phase if that slab ended one
+            const bool drain_static = q > 0 && ((LASTMASK >> (q - 1)) & 1u);
+            const int dp = q > 0 ? phase_of(q - 1) : phase_of(NSLAB - 1);
+            const int db = q > 0 ? b : pb;
+            bf16x8 pv[2], wv[2][TN];
+            pv[0] = *reinterpret_cast<const bf16x8*>(hp_);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wv[0][j] = *reinterpret_cast<const bf16x8*>(wp_ + j * 32 * RS);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) {
+                    pv[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(hp_ + 32 * (s + 1));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        wv[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(wp_ + j * 32 * RS + 32 * (s + 1));
+                }
+                if (s <= NI && (drain_static || (q == 0 && have_prev))) {   // drain slot s of NI + 1: patch -> HBM
+                    if (s > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(db, dp, s - 1)) = dreg;
+                    if (s < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (s * PPI + sp) * SRS + sc8 * 16);
+                }
+                // the next image's halo, in the image's first two slabs
+                if (q == 0 && s < HV) load_halo_vec(nb, s);
+                if (q == 1 && KS + s < HV) load_halo_vec(nb, KS + s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[s & 1][j], pv[s & 1], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (last_tap) {
+                // ---- the phase is finished: ReLU, bf16, park in the patch (drained inside the next slab) ----
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float v = acc[j][4 * g + k];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            o[k] = (bf16)v;
+                        }
+                        *reinterpret_cast<bf16x4*>(stg + r * SRS + (j * 32 + 8 * g + 4 * h) * 2) = o;
+                    }
+                wave_lds_fence();
+            }
+            store_slab((q + 1) % RING, buf ^ 1);           // slab q + 1: that buffer was last read before the previous barrier
+            __syncthreads();
+        }
+        have_prev = true; pb = b;
+        if (NSLAB & 1) par ^= 1;
+    }
+    if (chunk_live) {                                      // the last phase of the last image
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<u32x4*>(outb + out_off(pb, phase_of(NSLAB - 1), i)) =
+                *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
+    }
+}
+
+template <int CIN, int NT>
+static constexpr int image_lds_bytes() {
+    return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + NT * 4 + 8 * 32 * (NT * 2 + 16) + (16 * 4 + 4 * 2) * 4;
+}
+
+// Slab structure of a plan this kernel is built for: a transposed gather over 16x16 phase grids with 128 gathered and
+// <= 64 produced channels whose (slabs per image, last-tap mask) is one of the compiled pairs.  0 slabs: not applicable.
+struct ImageGeom { int nslab; unsigned lastmask; };
+static ImageGeom image_geom(const GemmPlan& P) {
+    const ImageGeom none = {0, 0u};
+    if (P.CgS != 128 || P.Npad != 64 || P.Hin != 16 || P.Win != 16 || P.nphase < 1) return none;
+    ImageGeom g = {0, 0u};
+    for (int i = 0; i < P.nphase; ++i) {
+        const Phase& ph = P.ph[i];
+        if (ph.SY != 1 || ph.SX != 1 || ph.Hg != 16 || ph.Wg != 16 || ph.ntaps < 1) return none;
+        if (ph.DSY != P.ph[0].DSY || ph.DSX != P.ph[0].DSY) return none;
+        for (int t = 0; t < ph.ntaps; ++t)
+            if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return none;
+        g.nslab += ph.ntaps;
+        if (g.nslab > 16) return none;
+        g.lastmask |= 1u << (g.nslab - 1);
+    }
+    const bool built = (g.nslab == 16 && g.lastmask == 0x8888u) ||     // ConvTranspose2d k4 s2 p1 forward
+                       (g.nslab == 9 && g.lastmask == 0x115u);         // Conv2d k3 s2 p1 input-gradient
+    return built ? g : none;
+}
+static bool image_applicable(const GemmPlan& P) { return image_geom(P).nslab != 0; }
+
+static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
+                                  const float* shift, const void* res, int relu, int accumulate, int out_f32,
+                                  hipStream_t st) {
+    const ImageGeom g = image_geom(P);
+    if (scale || res || accumulate || out_f32 || !g.nslab) return false;
+    ImageConvArgs a;
+    a.in = in; a.wp = wp; a.out = out; a.shift = shift; a.relu = relu;
+    a.B = P.B; a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    memset(a.slab_toff, 0, sizeof(a.slab_toff)); memset(a.slab_k0, 0, sizeof(a.slab_k0));
+    memset(a.slab_phase, 0, sizeof(a.slab_phase)); memset(a.phase_d0y, 0, sizeof(a.phase_d0y)); memset(a.phase_d0x, 0, sizeof(a.phase_d0x));
+    a.nslab = 0; a.DS = P.ph[0].DSY;
+    for (int i = 0; i < P.nphase; ++i) {
+        const Phase& ph = P.ph[i];
+        a.phase_d0y[i] = ph.D0Y; a.phase_d0x[i] = ph.D0X;
+        for (int t = 0; t < ph.ntaps; ++t, ++a.nslab) {
+            a.slab_toff[a.nslab] = (int)ph.dy[t] * 18 + (int)ph.dx[t];
+            a.slab_k0[a.nslab] = ph.koff + t * 128;
+            a.slab_phase[a.nslab] = i << 1 | (t + 1 == ph.ntaps ? 1 : 0);
+        }
+    }
+    constexpr int lds = image_lds_bytes<128, 64>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    dim3 grid(P.B < 256 ? P.B : 256), block(512);
+#define IMAGE_CASE(NS_, MASK_)                                                                                      \
+    if (g.nslab == NS_ && g.lastmask == MASK_) {                                                                    \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, NS_, MASK_>),  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                             \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, NS_, MASK_>), grid, block, lds, st, a);                 \
+        return true;                                                                                                \
+    }
+    IMAGE_CASE(16, 0x8888u) IMAGE_CASE(9, 0x115u)
+#undef IMAGE_CASE
+    return false;
+}
+
+}  // namespace dvae

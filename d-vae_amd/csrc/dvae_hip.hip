@@ -4,6 +4,7 @@
 #include "elementwise.hpp"
 #include "igemm.hpp"
 #include "conv_halo.hpp"
+#include "conv_image.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -134,6 +135,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     }
     if (e.in_scale_shift || e.out_stats)                  // the gather GEMM has neither: never drop them silently
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation / output statistics unavailable for this launch");
+    if (try_launch_image_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_image");
+        return DVAE_OK;
+    }
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
 }
 
@@ -153,6 +158,10 @@ int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, co
         return launch_igemm<float>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 1, S(st));
     if (try_launch_halo_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
         DVAE_CHECK_LAUNCH("conv_halo");
+        return DVAE_OK;
+    }
+    if (try_launch_image_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_image");
         return DVAE_OK;
     }
     return launch_igemm<bf16>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st));
