@@ -116,17 +116,26 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     const unsigned char* wrow = wbuf + r * RS + 16 * h;
     const int sp = lane / VPS, sc8 = lane % VPS;           // coalesced side: lane = (pixel sp of a PPI group, 8-channel chunk sc8)
     const bool chunk_live = sc8 * 8 < a.NS;
-    auto out_off = [&](int b, int p, int i) -> long {      // this lane's 16-byte piece i of phase p's output rows
+    // output pixel of this lane's 16-byte piece i, relative to the phase's first pixel; and each phase's first pixel
+    // relative to the image (uniform, kept in scalar registers: the drain slots sit between MFMAs and must not wait on LDS)
+    int lpix[NI], d0[4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
         const int q = i * PPI + sp;                        // pixel of the wave's 32
-        const int oy = (2 * wave + (q >> 4)) * a.DS + tab[64 + p * 2], ox = (q & 15) * a.DS + tab[64 + p * 2 + 1];
-        return ((long)(b * a.Hout + oy) * a.Wout + ox) * a.NS + sc8 * 8;
+        lpix[i] = ((2 * wave + (q >> 4)) * a.Wout + (q & 15)) * a.DS;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        d0[p] = __builtin_amdgcn_readfirstlane(tab[64 + p * 2]) * a.Wout + __builtin_amdgcn_readfirstlane(tab[64 + p * 2 + 1]);
+    auto out_off = [&](int b, int p, int i) -> long {      // p, i: compile-time at every call site
+        return ((long)b * (a.Hout * a.Wout) + d0[p] + lpix[i]) * a.NS + sc8 * 8;
     };
     auto wave_lds_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto phase_of = [](int q) { int p = 0; for (int i = 0; i < q; ++i) p += (LASTMASK >> i) & 1u; return p; };
+    auto phase_of = [](int q) { return __builtin_popcount(LASTMASK & ((1u << q) - 1u)); };
 
     const int G = gridDim.x;
     int b = blockIdx.x;
