@@ -57,7 +57,9 @@ __device__ __forceinline__ float dpp_f(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
 
-template <int CIN, int NT, int TW>
+// IN_SS / STATS: compiled-in support for the input-normalisation prologue / the output statistics (their registers
+// are only paid for where a launch uses them).
+template <int CIN, int NT, int TW, bool IN_SS, bool STATS>
 __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     constexpr int TH = 256 / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
     constexpr int RS = CIN * 2 + 16;          // bytes per staged halo pixel (16-byte pad spreads banks)
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         tile_origin(tile, y0, x0, b);
         if (k == 0) {
             inimg = 0;
-            if (a.in_ss) {
+            if (IN_SS && a.in_ss) {
                 const float* p = a.in_ss + (long)b * 2 * CIN + (tid % VPP) * 8;
                 isc[0] = *reinterpret_cast<const f32x4*>(p); isc[1] = *reinterpret_cast<const f32x4*>(p + 4);
                 ish[0] = *reinterpret_cast<const f32x4*>(p + CIN); ish[1] = *reinterpret_cast<const f32x4*>(p + CIN + 4);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
             const int v = tid + 512 * k;
             if (v >= HP * VPP) continue;
             u32x4 val = hreg[k];
-            if (a.in_ss && (inimg >> k & 1u)) {           // zero padding stays zero: it pads the normalised tensor
+            if (IN_SS && a.in_ss && (inimg >> k & 1u)) {  // zero padding stays zero: it pads the normalised tensor
                 bf16x8 x = *reinterpret_cast<bf16x8*>(&val);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -240,16 +242,16 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         auto mem_op = [&](int q) {
             if (q <= NI) {
                 if (drain) {
-                    if (q == 0 && a.stats) {
+                    if (q == 0 && STATS && a.stats) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
                     }
                     if (q > 0) {
                         if (chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(prev, q - 1)) = dreg;
-                        if (a.stats) stats_add(dreg);
+                        if (STATS && a.stats) stats_add(dreg);
                     }
                     if (q < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16);
-                    if (q == NI && a.stats) stats_flush(prev);
+                    if (q == NI && STATS && a.stats) stats_flush(prev);
                 }
             } else if (q <= 2 * NI) {
                 const int i = q - NI - 1;
@@ -380,9 +382,9 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         for (int i = 0; i < NI; ++i) {
             const u32x4 piece = *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
             if (chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(last, i)) = piece;
-            if (a.stats) stats_add(piece);
+            if (STATS && a.stats) stats_add(piece);
         }
-        if (a.stats) stats_flush(last);
+        if (STATS && a.stats) stats_flush(last);
     }
 }
 #undef HALO_STAMP
@@ -419,6 +421,8 @@ static HaloGeom halo_geom(const GemmPlan& P) {
 
 // true if the plan runs on the halo kernel
 static bool halo_applicable(const GemmPlan& P) { return halo_geom(P).TW != 0; }
+// ... and with the input-normalisation prologue / output statistics (built for 32-wide tiles only)
+static bool halo_features_applicable(const GemmPlan& P) { return halo_geom(P).TW == 32; }
 
 static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                  const float* shift, const void* res, int relu, int accumulate, int out_f32,
@@ -433,6 +437,7 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift;
     a.add = res ? res : (accumulate ? out : nullptr); a.add_after_relu = accumulate ? 1 : 0;
     if (stats && out_f32) return false;                   // statistics ride on the bf16 drain
+    if ((stats || in_ss) && hg.TW != 32) return false;
     a.in_ss = in_ss; a.in_relu = in_relu; a.stamps = stamps; a.stats = stats;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.out_f32 = out_f32;
@@ -441,21 +446,24 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     const int ntiles = P.B << (a.lx + a.ly);
     // one persistent workgroup per CU (its LDS footprint allows no more); tiles are strided over the grid
     dim3 grid(ntiles < 256 ? ntiles : 256, P.Npad / NT), block(512);
-#define HALO_CASE(C, N, T)                                                                                   \
-    if (P.CgS == C && NT == N && TW == T) {                                                                  \
+    const bool f_in = in_ss != nullptr, f_st = stats != nullptr;
+#define HALO_CASE(C, N, T, FI, FS)                                                                           \
+    if (P.CgS == C && NT == N && TW == T && f_in == FI && f_st == FS) {                                      \
         constexpr int lds = halo_lds_bytes<C, N, T>();                                                       \
         if (lds > HALO_LDS_MAX) return false;                                                                \
         static bool attr_set = false;                                                                        \
         if (!attr_set) {                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16_kernel<C, N, T>),        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16_kernel<C, N, T, FI, FS>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
             attr_set = true;                                                                                 \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<C, N, T>), grid, block, lds, st, a);                       \
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<C, N, T, FI, FS>), grid, block, lds, st, a);               \
         return true;                                                                                         \
     }
-    HALO_CASE(64, 64, 32) HALO_CASE(64, 32, 32) HALO_CASE(32, 64, 32) HALO_CASE(32, 32, 32)
-    HALO_CASE(64, 64, 16) HALO_CASE(64, 32, 16) HALO_CASE(32, 64, 16) HALO_CASE(32, 32, 16)
+#define HALO_SHAPES(T, FI, FS) HALO_CASE(64, 64, T, FI, FS) HALO_CASE(64, 32, T, FI, FS) HALO_CASE(32, 64, T, FI, FS) HALO_CASE(32, 32, T, FI, FS)
+    HALO_SHAPES(32, false, false) HALO_SHAPES(32, false, true) HALO_SHAPES(32, true, false) HALO_SHAPES(32, true, true)
+    HALO_SHAPES(16, false, false)
+#undef HALO_SHAPES
 #undef HALO_CASE
     return false;
 }

@@ -120,10 +120,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     if (rc) return rc;
     dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr};
     if (ep) e = *ep;
-    if (e.out_stats && (dtype != DVAE_BF16 || e.out_f32 || !halo_applicable(P)))
+    if (e.out_stats && (dtype != DVAE_BF16 || e.out_f32 || !halo_features_applicable(P)))
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused output statistics are not available for this shape/dtype "
                                "(see dvae_conv_out_stats_floats)");
-    if (e.in_scale_shift && (dtype != DVAE_BF16 || !halo_applicable(P)))
+    if (e.in_scale_shift && (dtype != DVAE_BF16 || !halo_features_applicable(P)))
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation is not available for this shape/dtype "
                                "(see dvae_conv_supports_input_norm)");
     if (dtype == DVAE_F32)
@@ -145,7 +145,7 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
 int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype) {
     GemmPlan P;
     if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P)) return 0;
-    return halo_applicable(P) ? 1 : 0;
+    return halo_features_applicable(P) ? 1 : 0;
 }
 
 int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, const dvae_conv_desc* d, int dtype,
@@ -280,7 +280,7 @@ int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, fl
 
 size_t dvae_conv_out_stats_floats(const dvae_conv_desc* d, int dtype) {
     GemmPlan P;
-    if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P) || !halo_applicable(P)) return 0;
+    if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P) || !halo_features_applicable(P)) return 0;
     return (size_t)P.B * (P.Hout * P.Wout / 32) * 2 * P.NS;
 }
 

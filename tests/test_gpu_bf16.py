@@ -240,7 +240,7 @@ def test_fused_encoder_head_bf16(B, Ld):
     assert rel_err(from_act(z, Ld), z_ref) < 6e-3
 
 
-@pytest.mark.parametrize("cin,cout,hin,tr", [(64, 64, 32, True), (64, 32, 32, True), (64, 64, 16, False)])
+@pytest.mark.parametrize("cin,cout,hin,tr", [(64, 64, 32, True), (64, 32, 32, True), (32, 64, 64, False)])
 def test_conv_output_statistics_bf16(cin, cout, hin, tr):
     """InstanceNorm2d statistics (resnet.py:2030-2046) gathered by the producing conv's store against the
     stand-alone statistics kernel on the stored tensor: same values up to fp32 summation order."""
