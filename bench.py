@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--images", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the train step launch by launch instead of replaying HIP graphs")
     ap.add_argument("--no-purify", action="store_true", help="profiling aid: skip the purification region")
     return ap.parse_args()
 
@@ -162,8 +163,9 @@ def main():
             lo = (i * Bt) % (n_local - Bt)
             sel = idx[lo:lo + Bt]
             x0 = eng.input_from_u8(data, 0, Bt, index=sel)
-            eps = eng.eps_philox(Bt, index=sel, stream_id=100 + i)
-            eng.train_step(x0, labels[sel.long()], eps, Bt, 11, 3.0, 0.01, allreduce, world)
+            eps = eng.eps_philox(Bt, index=sel, stream_id=100)
+            step = eng.train_step if a.no_graph else eng.train_step_graphed
+            step(x0, labels[sel.long()], eps, Bt, 11, 3.0, 0.01, allreduce, world)
 
         for i in range(a.warmup):
             train_step(i)

@@ -191,6 +191,10 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     a.CdS = W.CdS; a.ntaps = W.ntaps;
     memcpy(a.dy, W.dy, 16); memcpy(a.dx, W.dx, 16);
     a.M = W.M; a.chunk_rows = W.chunk_rows; a.Kpad = W.Kpad; a.CdPad = W.CdPad;
+    float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
+    const bool fused = db && wgrad_bias_fused(W);
+    a.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
+    a.bias_taps = W.bias_taps; a.bpart = part;
     if (dtype == DVAE_F32)
         hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
     else
@@ -201,10 +205,14 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     r.cx_log2 = W.cx_log2; r.Cd = W.Cd; r.ntaps = W.ntaps; r.sX = W.sX; r.sD = W.sD;
     memcpy(r.woff, W.woff, sizeof(r.woff));
     const long tot = (long)W.Kpad * W.CdPad;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, S(st), r);
+    r.nmain = (int)((tot + 63) / 64);
+    r.bpart = part; r.db = db; r.bias_mode = a.bias_mode; r.bwidth = wgrad_bias_width(W); r.Cb = d->Cout; r.cxs = W.CxS;
+    r.nbt = 0;
+    for (int t = 0; t < W.ntaps && r.nbt < 4; ++t)
+        if (W.bias_taps >> t & 1u) r.btap[r.nbt++] = t;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.nmain + (fused ? (d->Cout + 15) / 16 : 0)), dim3(256), 0, S(st), r);
     DVAE_CHECK_LAUNCH("wgrad_reduce");
-    if (db) {
-        float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
+    if (db && !fused) {
         const void* src = dy;
         const int CS = W.bias_from_gathered ? W.CxS : W.CdS;
         const int rows = W.bias_from_gathered ? W.B * W.Hx * W.Wx : W.M;

@@ -640,6 +640,7 @@ struct WgradPlan {
     int sX, sD;                     // reference weight index = cd*sD + cx*sX + woff
     int M, S, chunk_rows, Kpad, CdPad;
     int bias_from_gathered;         // bias gradient = column sums of the gathered (1) or dense (0) tensor
+    unsigned bias_taps;             // gathered case: the taps that together read every pixel exactly once (0: none known)
 };
 
 static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
@@ -668,6 +669,12 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
             W.dy[t] = (signed char)(ky - p); W.dx[t] = (signed char)(kx - p); W.woff[t] = t;
         }
     W.M = d.B * W.Hg * W.Wg;
+    if (W.Hx == W.Hg * s && W.Wx == W.Wg * s) {
+        int n = 0;
+        for (int t = 0; t < kk; ++t)
+            if (W.dy[t] >= 0 && W.dy[t] < s && W.dx[t] >= 0 && W.dx[t] < s) { W.bias_taps |= 1u << t; ++n; }
+        if (n != s * s) W.bias_taps = 0;
+    }
     W.Kpad = round_up(kk * W.CxS, 64);
     W.CdPad = round_up(W.CdS, 64);
     const int tiles = (W.Kpad / 64) * (W.CdPad / 64);
@@ -680,9 +687,17 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
 
 constexpr int COLSUM_BLOCKS = 128;
 
+// the bias gradient rides on the weight-gradient launches (column sums of the tiles they stage anyway) unless the
+// bias comes from the gathered tensor and no set of taps reads each of its pixels exactly once
+static bool wgrad_bias_fused(const WgradPlan& W) {
+    return !W.bias_from_gathered || (W.bias_taps != 0 && W.SY * W.SX <= 4);
+}
+static int wgrad_bias_width(const WgradPlan& W) { return W.bias_from_gathered ? W.Kpad : W.CdPad; }
+
 static size_t wgrad_workspace_floats(const WgradPlan& W) {
     const int cs = W.bias_from_gathered ? W.CxS : W.CdS;
-    return (size_t)W.S * W.Kpad * W.CdPad + (size_t)COLSUM_BLOCKS * cs;
+    const size_t fused = (size_t)W.S * wgrad_bias_width(W), split = (size_t)COLSUM_BLOCKS * cs;
+    return (size_t)W.S * W.Kpad * W.CdPad + (fused > split ? fused : split);
 }
 
 struct WgradArgs {
@@ -692,7 +707,26 @@ struct WgradArgs {
     int B, Hx, Wx, cx_log2, Hg, Wg, SY, SX, CdS, ntaps;
     signed char dy[16], dx[16];
     int M, chunk_rows, Kpad, CdPad;
+    // bias gradient: 0 none; 1 column sums of d (by the workgroups of K slab 0); 2 column sums of the gathered
+    // tensor over the taps in bias_taps (by the workgroups of Cd slab 0).  Partials go to bpart[chunk][width].
+    int bias_mode;
+    unsigned bias_taps;
+    float* bpart;
 };
+
+// Column sums of the rows a workgroup staged, from the per-thread sums bs[V] (V channels at column kv * V, RL row
+// lanes): reduced over the row lanes in LDS in a fixed order and written as one 64-wide partial row.
+template <int V, int RL>
+__device__ inline void wgrad_bias_flush(const float* bs, float* red, int kv, int rl, float* out) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[rl * 64 + kv * V + i] = bs[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int q = 0; q < RL; ++q) t += red[q * 64 + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
 
 // fp32: one 64(K) x 64(Cd) slab tile per workgroup, contraction over a chunk of pixels,
 // 32 pixels per LDS stage, v_mfma_f32_32x32x2_f32 with A[i = K column][k = pixel], B[k = pixel][j = cd].
@@ -734,12 +768,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel_f32(const WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
+    const bool bias_d = a.bias_mode == 1 && blockIdx.y == 0, bias_x = a.bias_mode == 2 && blockIdx.z == 0;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
     if (mbeg < mend) load(mbeg);
     for (int mb = mbeg; mb < mend; mb += 32) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<f32x4*>(&As[(rl + 16 * i) * 64 + kv * 4]) = xr[i];
             *reinterpret_cast<f32x4*>(&Ds[(rl + 16 * i) * 64 + kv * 4]) = dr[i];
+            if (bias_d || bias_x) {
+                const f32x4 v = bias_d ? dr[i] : xr[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bs[c] += v[c];
+            }
         }
         __syncthreads();
         if (mb + 32 < mend) load(mb + 32);
@@ -754,6 +795,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel_f32(const WgradArgs a) {
     float* ws = a.ws + ((long)blockIdx.x * a.Kpad + kbase + wi * 32) * a.CdPad + cdbase + wj * 32 + r;
 #pragma unroll
     for (int e = 0; e < 16; ++e) ws[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * a.CdPad] = acc[e];
+    if (bias_d) wgrad_bias_flush<4, 16>(bs, As, kv, rl, a.bpart + (long)blockIdx.x * a.CdPad + cdbase);
+    if (bias_x) wgrad_bias_flush<4, 16>(bs, As, kv, rl, a.bpart + (long)blockIdx.x * a.Kpad + kbase);
 }
 
 // bf16: same decomposition; 64 pixels per LDS stage in [pixel][channel] order (192-byte rows: the four
@@ -806,12 +849,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(const WgradArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const bool bias_d = a.bias_mode == 1 && blockIdx.y == 0, bias_x = a.bias_mode == 2 && blockIdx.z == 0;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (mbeg < mend) load(mbeg);
     for (int mb = mbeg; mb < mend; mb += MS) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<u32x4*>(As + (rl + 32 * i) * RS + kv * 16) = xr[i];
             *reinterpret_cast<u32x4*>(Ds + (rl + 32 * i) * RS + kv * 16) = dr[i];
+            if (bias_d || bias_x) {
+                const u32x4 v = bias_d ? dr[i] : xr[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {      // a bf16 is the high half of its fp32
+                    bs[2 * c] += __uint_as_float(v[c] << 16);
+                    bs[2 * c + 1] += __uint_as_float(v[c] & 0xffff0000u);
+                }
+            }
         }
         __syncthreads();
         if (mb + MS < mend) load(mb + MS);
@@ -826,6 +879,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(const WgradArgs a) {
     float* ws = a.ws + ((long)blockIdx.x * a.Kpad + kbase + wi * 32) * a.CdPad + cdbase + wj * 32 + r;
 #pragma unroll
     for (int e = 0; e < 16; ++e) ws[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * a.CdPad] = acc[e];
+    float* red = reinterpret_cast<float*>(As);      // 32 x 64 floats; every wave is past the loop's last barrier
+    if (bias_d) wgrad_bias_flush<8, 32>(bs, red, kv, rl, a.bpart + (long)blockIdx.x * a.CdPad + cdbase);
+    if (bias_x) wgrad_bias_flush<8, 32>(bs, red, kv, rl, a.bpart + (long)blockIdx.x * a.Kpad + kbase);
 }
 
 struct WreduceArgs {
@@ -833,6 +889,11 @@ struct WreduceArgs {
     float* dw;
     int S, Kpad, CdPad, Cx, cx_log2, Cd, ntaps, sX, sD;
     int woff[16];
+    // bias partials [S][bwidth] -> db[Cb]; the workgroups from nmain on do this part
+    const float* bpart;
+    float* db;
+    int bias_mode, bwidth, Cb, cxs, nmain;
+    int nbt, btap[4];                // gathered case: the (at most 4) taps whose column sums add up to the bias gradient
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
@@ -841,6 +902,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
     __shared__ float part[4][64];
     const long total = (long)a.Kpad * a.CdPad;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= a.nmain) {                // bias gradient: 16 channels per workgroup, 16 lanes split S
+        const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const int c = ((int)blockIdx.x - a.nmain) * 16 + cl;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < a.Cb) {
+            if (a.bias_mode == 1) {
+                for (int i = rl; i < a.S; i += 64) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i + 16 * u < a.S) s[u] += a.bpart[(long)(i + 16 * u) * a.bwidth + c];
+                }
+            } else {
+                for (int i = rl; i < a.S; i += 16) {
+                    const float* row = a.bpart + (long)i * a.bwidth + c;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < a.nbt) s[u] += row[a.btap[u] * a.cxs];
+                }
+            }
+        }
+        float* red = &part[0][0];
+        red[rl * 16 + cl] = (s[0] + s[1]) + (s[2] + s[3]);
+        __syncthreads();
+        if (rl == 0 && c < a.Cb) {
+            float t = 0.f;
+            for (int q = 0; q < 16; ++q) t += red[q * 16 + cl];
+            a.db[c] = t;
+        }
+        return;
+    }
     const long e = (long)blockIdx.x * 64 + el;
     float s0 = 0.f, s1 = 0.f;
     if (e < total) {

@@ -750,6 +750,59 @@ class DVAEEngine:
             allreduce(self.G)
         self.adam_step()
 
+    def train_step_graphed(self, x0, y, eps, b, epoch, kld_target, kld_weight, allreduce=None, world=1):
+        """train_step() replayed from captured HIP graphs: a step is ~200 short launches, and at the reference's batch
+        size the host cannot issue them as fast as the GPU retires them.  Everything a step reads lives in fixed
+        device buffers (activations, hyper-parameters, the Adam step count), so a capture stays valid from step to
+        step; the per-step values -- labels and the noise counters -- are copied into fixed buffers before the replay.
+        Between ranks the collectives stay outside the graphs (three segments: forward+loss sums | gate+backward |
+        clip+Adam).  The first call with a given (batch, gate, constants) runs eagerly, the second captures."""
+        if not isinstance(eps, PhiloxEps):
+            raise ValueError("train_step_graphed draws its noise in-kernel: pass eps_philox(...)")
+        if x0.data_ptr() != self.act("x0", self.S, 3).data_ptr():
+            raise ValueError("train_step_graphed reads the engine's own input buffer: build x0 with input_from_*()")
+        gy = self.buf("graph.y", (self.B,), torch.int64)
+        gi = self.buf("graph.index", (self.B,), torch.int32)
+        gy[:b].copy_(y)
+        if eps.index is not None:
+            gi[:b].copy_(eps.index[:b])
+        else:
+            torch.arange(eps.first, eps.first + b, device=self.dev, dtype=torch.int32, out=gi[:b])
+        geps = PhiloxEps(0, gi, eps.stream_id)
+        key = (b, epoch > 10, float(kld_target), float(kld_weight), world, eps.stream_id, allreduce is not None)
+        graphs = getattr(self, "_graphs", None)
+        if graphs is None:
+            graphs = self._graphs = {}
+        if not self.packed_valid:
+            self.pack_weights()
+        entry = graphs.get(key)
+        if entry is None:
+            graphs[key] = "warm"
+            self.train_step(x0, gy, geps, b, epoch, kld_target, kld_weight, allreduce, world)
+            return
+        if entry == "warm":
+            segs = [lambda: (self.forward(x0, gy, geps, b, True), self.loss_sums()),
+                    lambda: (self.loss_gate(epoch, kld_target, kld_weight, world), self.backward()),
+                    self.adam_step]
+            if allreduce is None:
+                segs = [lambda s=segs: [f() for f in s]]
+            entry = []
+            for f in segs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    f()
+                entry.append(g)
+            graphs[key] = entry
+        if allreduce is None:
+            entry[0].replay()
+        else:
+            entry[0].replay()
+            allreduce(self.sums)
+            entry[1].replay()
+            allreduce(self.G)
+            entry[2].replay()
+        self.packed_valid, self.fold_valid = True, False
+
     def purify_batch(self, data_u8, out_u8, noise_out, labels, first, b, stage, eps_nchw=None, global_first=None,
                      skip_unread=False):
         """Purify images [first, first+b) of the resident uint8 set (main_vae_disentangle.py:59-69).

@@ -280,3 +280,30 @@ def test_conv_output_statistics_bf16(cin, cout, hin, tr):
     # and against torch on the stored values
     y = from_act(ya, cout).float()
     assert rel_err(out["fused"][0][:, :cout].cpu(), y.mean(dim=(2, 3))) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [L.BF16, L.F32])
+def test_graphed_train_steps_equal_eager_steps(dtype):
+    """Four steps replayed from captured graphs leave exactly the parameters, Adam moments, BatchNorm buffers and
+    loss scalars that four launch-by-launch steps leave (no kernel on the path uses atomics, so runs are repeatable)."""
+    B = 8
+    ocfg = O.DVAEConfig()
+    g = torch.Generator().manual_seed(5)
+    xs = torch.rand(4, B, 3, 32, 32, generator=g).cuda()
+    ys = torch.randint(0, 10, (4, B), generator=g).cuda()
+    ends = []
+    for graphed in (False, True):
+        _, eng, _ = _engine(dtype, B)
+        eng.set_hyper(lr=5e-3, max_norm=5.0, grad_scale=1.0, steps_done=0)
+        scal = []
+        for i in range(4):
+            x0 = eng.input_from_nchw(xs[i])
+            eps = eng.eps_philox(B, first=i * B, stream_id=12)
+            step = eng.train_step_graphed if graphed else eng.train_step
+            step(x0, ys[i], eps, B, 11, 3.0, 0.01)
+            scal.append(eng.scal.clone())
+        torch.cuda.synchronize()
+        ends.append((eng.P.clone(), eng.M.clone(), eng.V.clone(), eng.R.clone(), torch.stack(scal), eng.hyper.clone()))
+    for a, b in zip(*ends):
+        assert torch.equal(a, b)
+    assert float(ends[0][5][6]) == 4.0          # the Adam step count advanced on the device in both modes
