@@ -252,6 +252,20 @@ int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* ga
     if (rc) return rc;
     const NormGeom g = norm_geom(groups, rows_per_group, C);
     if (ws_bytes < norm_ws_floats(g) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "norm workspace too small");
+    // InstanceNorm of images that fit the registers of one workgroup: one launch, one read, one write
+    const bool image_ok = dtype == DVAE_BF16 && groups > 1 && !res && !gamma && !beta && !running_mean;
+    const ImageNormPlan ip = image_ok ? in_image_plan(rows_per_group, C) : ImageNormPlan{0, 0};
+    if (ip.nv) {
+        const dim3 grid(groups, ip.split);
+        if (ip.nv == 4)
+            hipLaunchKernelGGL((in_image_fwd_kernel<4>), grid, dim3(512), 0, S(st), (const bf16*)x, (bf16*)y, save_mean,
+                               save_invstd, rows_per_group, C, eps, relu);
+        else
+            hipLaunchKernelGGL((in_image_fwd_kernel<8>), grid, dim3(512), 0, S(st), (const bf16*)x, (bf16*)y, save_mean,
+                               save_invstd, rows_per_group, C, eps, relu);
+        DVAE_CHECK_LAUNCH("in_image_fwd");
+        return DVAE_OK;
+    }
     float* partial = (float*)ws;
     float* scale_shift = partial + (size_t)groups * g.nchunk * 3 * C + (size_t)groups * 3 * C;
     const long nvec = (long)groups * rows_per_group * C / (dtype == DVAE_BF16 ? 8 : 4);
@@ -340,6 +354,19 @@ int dvae_norm_bwd(const void* dy, const void* y, const void* x, void* dx, void* 
     if ((dgamma || dbeta) && groups != 1) DVAE_FAIL(DVAE_EINVAL, "affine gradients need a single group");
     const NormGeom g = norm_geom(groups, rows_per_group, C);
     if (ws_bytes < norm_ws_floats(g) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "norm workspace too small");
+    const ImageNormPlan ip = (dtype == DVAE_BF16 && groups > 1 && !dres && !gamma) ? in_image_plan(rows_per_group, C)
+                                                                                     : ImageNormPlan{0, 0};
+    if (ip.nv) {
+        const dim3 grid(groups, ip.split);
+        if (ip.nv == 4)
+            hipLaunchKernelGGL((in_image_bwd_kernel<4>), grid, dim3(512), 0, S(st), (const bf16*)dy, (const bf16*)y,
+                               (const bf16*)x, (bf16*)dx, save_mean, save_invstd, rows_per_group, C, relu);
+        else
+            hipLaunchKernelGGL((in_image_bwd_kernel<8>), grid, dim3(512), 0, S(st), (const bf16*)dy, (const bf16*)y,
+                               (const bf16*)x, (bf16*)dx, save_mean, save_invstd, rows_per_group, C, relu);
+        DVAE_CHECK_LAUNCH("in_image_bwd");
+        return DVAE_OK;
+    }
     float* partial = (float*)ws;
     float* coef = partial + (size_t)groups * g.nchunk * 3 * C;
     const long nvec = (long)groups * rows_per_group * C / (dtype == DVAE_BF16 ? 8 : 4);

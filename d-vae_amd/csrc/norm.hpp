@@ -389,4 +389,193 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* dy, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm of small images (bf16, no affine), one workgroup per (image, block of channels): its share of the image
+// sits in the registers of its 512 threads (NV 16-byte vectors each), so the forward is one read and one write of the
+// tensor and the backward one read of each operand -- against three launches and two to three reads for the chunked
+// kernels above.  gridDim.y workgroups split the channels of an image (channels are independent), which halves the
+// registers per thread and doubles the workgroups of a small batch.  Thread t owns the vectors t + 512 k of its share:
+// always the same 8 channels (512 is a multiple of the vectors per row).  Statistics are two-pass in registers (mean,
+// then squared deviations), reduced wave-first then across the 8 waves in a fixed order; the split depends on the
+// shape only, so an image's result does not depend on what else is in the launch.
+// ------------------------------------------------------------------------------------------------
+__device__ inline float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ inline float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ inline unsigned bf_pack(float lo, float hi) {
+    const bf16 a = (bf16)lo, b = (bf16)hi;
+    return (unsigned)*reinterpret_cast<const unsigned short*>(&a) | ((unsigned)*reinterpret_cast<const unsigned short*>(&b) << 16);
+}
+
+// v[8]: per-thread sums of the thread's 8 channels -> sums over the whole workgroup, in every thread
+__device__ inline void image_channel_sum(float (&v)[8], float* red /* [8][128] */, int CV, int cvi) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int o = CV; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    }
+    if (lane < CV) {
+        *reinterpret_cast<f32x4*>(red + wave * 128 + cvi * 8) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(red + wave * 128 + cvi * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(red + w * 128 + cvi * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(red + w * 128 + cvi * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] += a[i]; v[4 + i] += b[i]; }
+    }
+}
+
+// element offset of the k-th vector of thread t: row (t + 512 k) / CV of the image, this workgroup's block of channels
+struct ImageShare {
+    int CV, cvi, C, c0;       // vectors per row of the share, the thread's vector in the row, channels, first channel
+    __device__ ImageShare(int C_) : C(C_) {
+        CV = (C_ >> 3) / gridDim.y;
+        cvi = threadIdx.x % CV;
+        c0 = (blockIdx.y * CV + cvi) * 8;
+    }
+    __device__ unsigned off(int k) const { return ((threadIdx.x + 512u * k) / (unsigned)CV) * (unsigned)C + (unsigned)c0; }
+};
+
+template <int NV>
+__global__ __launch_bounds__(512) void in_image_fwd_kernel(const bf16* x, bf16* y, float* save_mean, float* save_invstd,
+                                                           int rows, int C, float eps, int relu) {
+    __shared__ __attribute__((aligned(16))) float red[2][8 * 128];
+    const ImageShare sh(C);
+    const int tid = threadIdx.x, CV = sh.CV, cvi = sh.cvi;
+    const long base = (long)blockIdx.x * rows * C;
+    x += base; y += base;
+    u32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const u32x4*>(x + sh.off(k));
+    float m[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { m[2 * c] += bf_lo(v[k][c]); m[2 * c + 1] += bf_hi(v[k][c]); }
+    image_channel_sum(m, red[0], CV, cvi);
+    const float inv_n = 1.f / (float)rows;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { m[i] *= inv_n; q[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float a = bf_lo(v[k][c]) - m[2 * c], b = bf_hi(v[k][c]) - m[2 * c + 1];
+            q[2 * c] += a * a; q[2 * c + 1] += b * b;
+        }
+    image_channel_sum(q, red[1], CV, cvi);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)                      // keep the packed image, not its fp32 expansion, across the reduction
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[k][c]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = 1.0f / sqrtf(q[i] * inv_n + eps);
+    if (tid < CV) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            save_mean[(long)blockIdx.x * C + sh.c0 + i] = m[i];
+            save_invstd[(long)blockIdx.x * C + sh.c0 + i] = q[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = (bf_lo(v[k][c]) - m[2 * c]) * q[2 * c], b = (bf_hi(v[k][c]) - m[2 * c + 1]) * q[2 * c + 1];
+            if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+            o[c] = bf_pack(a, b);
+        }
+        *reinterpret_cast<u32x4*>(y + sh.off(k)) = o;
+    }
+}
+
+// dx = invstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * [y > 0], xhat = (x - mean) * invstd
+template <int NV>
+__global__ __launch_bounds__(512) void in_image_bwd_kernel(const bf16* dy, const bf16* y, const bf16* x, bf16* dx,
+                                                           const float* save_mean, const float* save_invstd, int rows,
+                                                           int C, int relu) {
+    __shared__ __attribute__((aligned(16))) float red[2][8 * 128];
+    const ImageShare sh(C);
+    const int CV = sh.CV, cvi = sh.cvi;
+    const long base = (long)blockIdx.x * rows * C;
+    dy += base; x += base; dx += base;
+    (void)y;
+    float mean[8], istd[8], s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mean[i] = save_mean[(long)blockIdx.x * C + sh.c0 + i];
+        istd[i] = save_invstd[(long)blockIdx.x * C + sh.c0 + i];
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    u32x4 g[NV], xr[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        g[k] = *reinterpret_cast<const u32x4*>(dy + sh.off(k));
+        xr[k] = *reinterpret_cast<const u32x4*>(x + sh.off(k));
+        if (relu) {
+            // Without an affine, y = relu((x - mean) * invstd) is positive exactly where x > mean (invstd > 0, and
+            // neither the fp32 product nor its bf16 rounding can flush a non-zero difference to zero), so the ReLU
+            // mask comes from x and y is never read.  The mask is folded into the stored gradient.
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned u = g[k][c];
+                if (!(bf_lo(xr[k][c]) > mean[2 * c])) u &= 0xffff0000u;
+                if (!(bf_hi(xr[k][c]) > mean[2 * c + 1])) u &= 0x0000ffffu;
+                g[k][c] = u;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ga = bf_lo(g[k][c]), gb = bf_hi(g[k][c]);
+            s1[2 * c] += ga; s1[2 * c + 1] += gb;
+            s2[2 * c] += ga * (bf_lo(xr[k][c]) - mean[2 * c]) * istd[2 * c];
+            s2[2 * c + 1] += gb * (bf_hi(xr[k][c]) - mean[2 * c + 1]) * istd[2 * c + 1];
+        }
+    image_channel_sum(s1, red[0], CV, cvi);
+    image_channel_sum(s2, red[1], CV, cvi);
+    // the packed registers are what stays live across the reductions: without this the compiler keeps the fp32
+    // expansions of both operands (4x the registers) to save the conversions below
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(g[k][c]), "+v"(xr[k][c]));
+    const float inv_n = 1.f / (float)rows;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] *= inv_n; s2[i] *= inv_n; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float xa = (bf_lo(xr[k][c]) - mean[2 * c]) * istd[2 * c];
+            const float xb = (bf_hi(xr[k][c]) - mean[2 * c + 1]) * istd[2 * c + 1];
+            o[c] = bf_pack(istd[2 * c] * (bf_lo(g[k][c]) - s1[2 * c] - xa * s2[2 * c]),
+                           istd[2 * c + 1] * (bf_hi(g[k][c]) - s1[2 * c + 1] - xb * s2[2 * c + 1]));
+        }
+        *reinterpret_cast<u32x4*>(dx + sh.off(k)) = o;
+    }
+}
+
+// per-image kernels for this shape: vectors per thread and workgroups per image (nv == 0: not applicable)
+struct ImageNormPlan { int nv, split; };
+static inline ImageNormPlan in_image_plan(int rows_per_group, int C) {
+    const long vecs = (long)rows_per_group * C / 8;
+    if (C < 16 || C > 128 || (C & (C - 1)) || vecs % 512) return {0, 0};
+    const long per = vecs / 512;                       // vectors per thread with one workgroup per image
+    if (per == 16) return {8, 2};
+    if (per == 8) return {4, 2};
+    if (per == 4) return {4, 1};
+    return {0, 0};
+}
+
 }  // namespace dvae

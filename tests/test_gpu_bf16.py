@@ -307,3 +307,37 @@ def test_graphed_train_steps_equal_eager_steps(dtype):
     for a, b in zip(*ends):
         assert torch.equal(a, b)
     assert float(ends[0][5][6]) == 4.0          # the Adam step count advanced on the device in both modes
+
+
+@pytest.mark.parametrize("B,hw,c", [(5, 32, 64), (3, 32, 32), (2, 16, 64)])
+def test_instance_norm_per_image_kernels_bf16(B, hw, c):
+    """InstanceNorm+ReLU of images that fit one workgroup's registers (one launch each way) against torch autograd
+    in fp32 on the same bf16-rounded inputs; an image's result must not depend on the rest of the batch."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(c + B)
+    x = (torch.randn(B, c, hw, hw, generator=g) * 1.5 + 0.3).bfloat16().float()
+    dy = torch.randn(B, c, hw, hw, generator=g).bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(F.instance_norm(xr, eps=1e-5))
+    yr.backward(dy)
+    xa, dya = to_act(x, L.BF16), to_act(dy, L.BF16)
+    ya, dxa = torch.empty_like(xa), torch.empty_like(xa)
+    mean = torch.empty(B, c, device="cuda")
+    invstd = torch.empty(B, c, device="cuda")
+    ws = torch.empty(lib.dvae_norm_workspace_bytes(B, hw * hw, c) // 4 + 16, device="cuda")
+    st = L.stream()
+
+    def run(n):
+        L.check(lib.dvae_norm_fwd_train(L.ptr(xa), None, L.ptr(ya), None, None, None, None, L.ptr(mean), L.ptr(invstd), L.ptr(ws),
+                                        ws.numel() * 4, n, hw * hw, c, 1, 0.0, 1e-5, L.BF16, st))
+        L.check(lib.dvae_norm_bwd(L.ptr(dya), L.ptr(ya), L.ptr(xa), L.ptr(dxa), None, None, L.ptr(mean), L.ptr(invstd), None, None,
+                                  L.ptr(ws), ws.numel() * 4, n, hw * hw, c, 1, L.BF16, st))
+    run(B)
+    y, dx = from_act(ya, c), from_act(dxa, c)
+    assert rel_err(y, yr.detach()) < 6e-3
+    assert rel_err(dx, xr.grad) < 8e-3
+    assert rel_err(mean.cpu(), x.mean(dim=(2, 3))) < 1e-5
+    y_all, dx_all = ya.clone(), dxa.clone()
+    ya.zero_(); dxa.zero_()
+    run(2)                                   # the first two images alone
+    assert torch.equal(ya[:2], y_all[:2]) and torch.equal(dxa[:2], dx_all[:2])
