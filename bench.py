@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--images", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (clean per-kernel timings)")
     ap.add_argument("--no-graph", action="store_true", help="issue the train step launch by launch instead of replaying HIP graphs")
     ap.add_argument("--no-purify", action="store_true", help="profiling aid: skip the purification region")
     return ap.parse_args()
@@ -103,6 +104,8 @@ def main():
     Bp = a.purify_batch
     eng = DVAEEngine(cfg, max(Bp, a.train_batch), "cuda", dtype, seed=0)
     init_params(eng)
+    if a.no_overlap:
+        eng._overlap = False
     n_local = max(Bp, (a.images + world - 1) // world)
     g = torch.Generator(device="cuda").manual_seed(rank)
     data = torch.randint(0, 256, (n_local, 32, 32, 3), generator=g, dtype=torch.uint8, device="cuda")

@@ -5,6 +5,7 @@
 #include "igemm.hpp"
 #include "conv_halo.hpp"
 #include "conv_image.hpp"
+#include "wgrad_halo.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -191,11 +192,25 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     a.CdS = W.CdS; a.ntaps = W.ntaps;
     memcpy(a.dy, W.dy, 16); memcpy(a.dx, W.dx, 16);
     a.M = W.M; a.chunk_rows = W.chunk_rows; a.Kpad = W.Kpad; a.CdPad = W.CdPad;
+    a.wg_log2 = a.hg_log2 = -1;
+    if (!(W.Wg & (W.Wg - 1)) && !(W.Hg & (W.Hg - 1))) { a.wg_log2 = ilog2_exact(W.Wg); a.hg_log2 = ilog2_exact(W.Hg); }
     float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
     const bool fused = db && wgrad_bias_fused(W);
     a.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
     a.bias_taps = W.bias_taps; a.bpart = part;
-    if (dtype == DVAE_F32)
+    if (W.halo) {
+        static bool lds_set = false;
+        if (!lds_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo_bf16_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
+            lds_set = true;
+        }
+        WgradHaloArgs h;
+        h.xg = (const bf16*)a.xg; h.d = (const bf16*)a.d; h.ws = a.ws;
+        h.H = W.Hg; h.W = W.Wg; h.tiles_x = W.Wg / 32; h.tiles_y = W.Hg / 4; h.ntiles = W.halo_tiles; h.per = W.halo_per;
+        h.bias_mode = a.bias_mode; h.bpart = a.bpart;
+        hipLaunchKernelGGL(wgrad_halo_bf16_kernel, dim3(W.S), dim3(256), WH_LDS, S(st), h);
+    } else if (dtype == DVAE_F32)
         hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
     else
         hipLaunchKernelGGL(wgrad_kernel_bf16, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);

@@ -641,6 +641,7 @@ struct WgradPlan {
     int M, S, chunk_rows, Kpad, CdPad;
     int bias_from_gathered;         // bias gradient = column sums of the gathered (1) or dense (0) tensor
     unsigned bias_taps;             // gathered case: the taps that together read every pixel exactly once (0: none known)
+    int halo, halo_tiles, halo_per; // all-taps-per-tile kernel (wgrad_halo.hpp): S workgroups of halo_per 4 x 32 tiles
 };
 
 static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
@@ -682,6 +683,19 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     int chunk = round_up((W.M + S - 1) / S, 64); if (chunk < 64) chunk = 64;
     W.chunk_rows = chunk;
     W.S = (W.M + chunk - 1) / chunk;
+    // 3x3 unit-stride 64 -> 64 in bf16: one staged tile serves all nine taps.  Each workgroup leaves a 147 KB slab for
+    // the reduction to read back, so at most one per two CUs, with at least 8 tiles each once there are enough.
+    bool halo = dtype == DVAE_BF16 && kk == 9 && s == 1 && p == 1 && W.CxS == 64 && W.CdS == 64 && W.Hx == W.Hg && W.Wx == W.Wg &&
+                W.Wg % 32 == 0 && W.Hg % 4 == 0 && (long)W.M * 64 <= 0x7fffffffL;
+    if (halo) {
+        W.halo = 1;
+        W.halo_tiles = d.B * (W.Hg / 4) * (W.Wg / 32);
+        int g = W.halo_tiles / 8;
+        if (g > 128) g = 128;
+        if (g < 1) g = 1;
+        W.halo_per = (W.halo_tiles + g - 1) / g;
+        W.S = (W.halo_tiles + W.halo_per - 1) / W.halo_per;
+    }
     return DVAE_OK;
 }
 
@@ -707,6 +721,7 @@ struct WgradArgs {
     int B, Hx, Wx, cx_log2, Hg, Wg, SY, SX, CdS, ntaps;
     signed char dy[16], dx[16];
     int M, chunk_rows, Kpad, CdPad;
+    int wg_log2, hg_log2;          // log2 of Wg / Hg when both are powers of two, else -1
     // bias gradient: 0 none; 1 column sums of d (by the workgroups of K slab 0); 2 column sums of the gathered
     // tensor over the taps in bias_taps (by the workgroups of Cd slab 0).  Partials go to bpart[chunk][width].
     int bias_mode;
@@ -753,7 +768,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel_f32(const WgradArgs a) {
             const int m = mb + rl + 16 * i;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
             if (m < mend) {
-                const int x = m % a.Wg, t = m / a.Wg, y = t % a.Hg, b = t / a.Hg;
+                int x, y, b;
+                if (a.wg_log2 >= 0) {                 // power-of-two maps: no integer division per row
+                    x = m & (a.Wg - 1); y = (m >> a.wg_log2) & (a.Hg - 1); b = m >> (a.wg_log2 + a.hg_log2);
+                } else {
+                    const int t = m / a.Wg;
+                    x = m % a.Wg; y = t % a.Hg; b = t / a.Hg;
+                }
                 const int iy = y * a.SY + dy, ix = x * a.SX + dx;
                 if (tv && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
                     xv = *reinterpret_cast<const f32x4*>(xg + (((long)((b * a.Hx + iy) * a.Wx + ix)) << a.cx_log2) + c);
@@ -835,7 +856,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(const WgradArgs a) {
             const int m = mb + rl + 32 * i;
             u32x4 xv = {0u, 0u, 0u, 0u}, dv = {0u, 0u, 0u, 0u};
             if (m < mend) {
-                const int x = m % a.Wg, t = m / a.Wg, y = t % a.Hg, b = t / a.Hg;
+                int x, y, b;
+                if (a.wg_log2 >= 0) {                 // power-of-two maps: no integer division per row
+                    x = m & (a.Wg - 1); y = (m >> a.wg_log2) & (a.Hg - 1); b = m >> (a.wg_log2 + a.hg_log2);
+                } else {
+                    const int t = m / a.Wg;
+                    x = m % a.Wg; y = t % a.Hg; b = t / a.Hg;
+                }
                 const int iy = y * a.SY + dy, ix = x * a.SX + dx;
                 if (tv && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
                     xv = *reinterpret_cast<const u32x4*>(xg + (((long)((b * a.Hx + iy) * a.Wx + ix)) << a.cx_log2) + c);

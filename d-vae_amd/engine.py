@@ -232,6 +232,7 @@ class DVAEEngine:
                                for n in ("decoder1.1", "decoder2.0"))
         self._fuse_head = bool(self.lib.dvae_fc_reparam_supported(C.byref(self._desc(self.specs["fc"], 1)), self.Ld, dtype))
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
+        self._overlap = self.dev.type == "cuda"   # weight gradients on a side stream (see _wgrad)
 
     # ------------------------------------------------------------------------------------------
     def _desc(self, sp: ConvSpec, b: int) -> ConvDesc:
@@ -348,7 +349,25 @@ class DVAEEngine:
         check(self.lib.dvae_conv_dgrad(ptr(dy), ptr(self.packed[(name, L.OP_DGRAD)]), ptr(dx), int(accumulate),
                                        C.byref(self.desc(name, b)), self.dtype, L.stream()))
 
+    def _side_stream(self):
+        st = getattr(self, "_side", None)
+        if st is None:
+            st = self._side = torch.cuda.Stream(device=self.dev)
+        return st
+
     def _wgrad(self, name, x, dy, b):
+        """Weight (and bias) gradient of one conv, issued on the side stream: nothing later in backward reads it, so it
+        runs next to the input-gradient chain (short, latency-bound launches) instead of in front of it.  All weight
+        gradients share one workspace and one stream, so they stay ordered among themselves; backward() joins the
+        side stream before it returns."""
+        if not self._overlap:
+            return self._wgrad_now(name, x, dy, b)
+        side = self._side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._wgrad_now(name, x, dy, b)
+
+    def _wgrad_now(self, name, x, dy, b):
         sp = self.specs[name]
         db = self.grad[name + ".bias"] if sp.bias else None
         check(self.lib.dvae_conv_wgrad(ptr(x), ptr(dy), ptr(self.grad[name + ".weight"]), ptr(db), ptr(self.wgrad_ws),
@@ -666,6 +685,8 @@ class DVAEEngine:
         d_c0 = self.act("g.conv1.out", S, 64)
         self._bn_bwd("bn1", d_out, self.act("bn1.out", S, 64), self.act("conv1.out", S, 64), d_c0, None, b * S * S, 64)
         self._wgrad("conv1", L_["x0"], d_c0, b)
+        if self._overlap:
+            torch.cuda.current_stream().wait_stream(self._side_stream())
 
     def _block_out_shape(self, blk):
         sp = self.specs[blk + ".conv1"]

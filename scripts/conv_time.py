@@ -1,6 +1,6 @@
 """Time one bf16 conv entry point at a given shape on the current library build.
 
-usage: python scripts/conv_time.py cin cout k stride pad transposed hin batch [dgrad]
+usage: python scripts/conv_time.py cin cout k stride pad transposed hin batch [dgrad|wgrad]
 """
 import ctypes as C
 import os
@@ -15,7 +15,8 @@ from dvae_amd import _lib as L  # noqa: E402
 
 def main():
     cin, cout, k, stride, pad, tr, hin, B = (int(v) for v in sys.argv[1:9])
-    dgrad = len(sys.argv) > 9
+    dgrad = len(sys.argv) > 9 and sys.argv[9] == "dgrad"
+    wgrad = len(sys.argv) > 9 and sys.argv[9] == "wgrad"
     lib = L.lib()
     d = L.ConvDesc(B, hin, hin, cin, cout, k, k, stride, pad, tr)
     ho = (hin - 1) * stride - 2 * pad + k if tr else (hin + 2 * pad - k) // stride + 1
@@ -29,8 +30,15 @@ def main():
     bias = torch.randn(cout, device="cuda")
     ep = L.Epilogue(None, bias.data_ptr(), None, 0, 0)
 
+    dw = torch.empty_like(w)
+    db = torch.empty(cout, device="cuda")
+    ws = torch.empty(lib.dvae_conv_wgrad_workspace_bytes(C.byref(d)) // 4 + 16, device="cuda")
+
     def run():
-        if dgrad:
+        if wgrad:
+            L.check(lib.dvae_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                        C.byref(d), L.BF16, st))
+        elif dgrad:
             L.check(lib.dvae_conv_dgrad(y.data_ptr(), pk.data_ptr(), x.data_ptr(), 0, C.byref(d), L.BF16, st))
         else:
             L.check(lib.dvae_conv_fwd(x.data_ptr(), pk.data_ptr(), C.byref(ep), y.data_ptr(), C.byref(d), L.BF16, st))
