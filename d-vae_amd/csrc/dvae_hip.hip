@@ -563,7 +563,8 @@ int dvae_sqnorm_partial(const float* g, int64_t n, float* partial, void* st) {
 int dvae_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, const float* partial,
                    float* scal, void* st) {
     if (n <= 0) DVAE_FAIL(DVAE_EINVAL, "clip_adam: empty");
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, S(st), p, g, m, v, (long)n, hyper,
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) DVAE_FAIL(DVAE_EINVAL, "clip_adam: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, S(st), p, g, m, v, (long)n, hyper,
                        partial, scal);
     DVAE_CHECK_LAUNCH("clip_adam");
     hipLaunchKernelGGL(hyper_tick_kernel, dim3(1), dim3(64), 0, S(st), hyper);

@@ -361,12 +361,34 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* p, const float* g
     const float total_norm = sqrtf(sq) * gs;
     const float coef = fminf(hyper[4] / (total_norm + 1e-6f), 1.0f) * gs;
     if (blockIdx.x == 0 && threadIdx.x == 0 && scal) scal[DVAE_SCAL_GRAD_NORM] = total_norm;
-    const double b1 = hyper[1], b2 = hyper[2];
-    const double t = (double)hyper[6] + 1.0;
-    const float bc2s = (float)sqrt(1.0 - pow(b2, t));
-    const float step_size = (float)((double)hyper[0] / (1.0 - pow(b1, t)));
+    // bias corrections in double (as the reference optimiser computes them), once per workgroup
+    __shared__ float corr[2];
+    if (threadIdx.x == 0) {
+        const double b1 = hyper[1], b2 = hyper[2];
+        const double t = (double)hyper[6] + 1.0;
+        corr[0] = (float)sqrt(1.0 - pow(b2, t));
+        corr[1] = (float)((double)hyper[0] / (1.0 - pow(b1, t)));
+    }
+    __syncthreads();
+    const float bc2s = corr[0], step_size = corr[1];
     const float fb1 = hyper[1], fb2 = hyper[2], eps = hyper[3];
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + i * 4);
+        f32x4 m4 = *reinterpret_cast<const f32x4*>(m + i * 4), v4 = *reinterpret_cast<const f32x4*>(v + i * 4);
+        f32x4 p4 = *reinterpret_cast<const f32x4*>(p + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gi = g4[k] * coef;
+            m4[k] = m4[k] * fb1 + (1.f - fb1) * gi;
+            v4[k] = v4[k] * fb2 + (1.f - fb2) * gi * gi;
+            p4[k] = p4[k] - step_size * m4[k] / (sqrtf(v4[k]) / bc2s + eps);
+        }
+        *reinterpret_cast<f32x4*>(m + i * 4) = m4;
+        *reinterpret_cast<f32x4*>(v + i * 4) = v4;
+        *reinterpret_cast<f32x4*>(p + i * 4) = p4;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * coef;
         const float mi = m[i] * fb1 + (1.f - fb1) * gi;
         const float vi = v[i] * fb2 + (1.f - fb2) * gi * gi;

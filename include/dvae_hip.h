@@ -212,7 +212,8 @@ int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out /
 
 /* ---- clip_grad_norm_ + Adam (main_vae_disentangle.py:210-211, resnet18DVAE.yaml:21-23) -------
  * hyper (device, fp32[8]): lr, beta1, beta2, eps, max_norm, grad_scale, steps_done, unused;
- * steps_done is incremented on the device after the update (graph-replay friendly). */
+ * steps_done is incremented on the device after the update (graph-replay friendly).
+ * p, g, m, v must be 16-byte aligned (DVAE_EINVAL otherwise). */
 int dvae_sqnorm_partial(const float* g, int64_t n, float* partial /* [DVAE_NPARTIAL] */, void* stream);
 int dvae_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float* hyper,
                    const float* partial, float* scal, void* stream);
