@@ -61,16 +61,24 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const T* x, float* part
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { s[i] = 0.f; ss[i] = 0.f; k0[i] = 0.f; }
-    for (int r = rl; r < nrows; r += RL) {
-        float v[VEC];
-        Act<T>::load(base + (long)r * C, v);
-        if (cnt == 0) {
+    // U rows per trip, their loads issued together (a load per trip would pay the memory latency once per row);
+    // rows past the end re-read the last row and are not accumulated.  The accumulation order is row order.
+    constexpr int U = 8;
+    for (int rb = rl; rb < nrows; rb += RL * U) {
+        float v[U][VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) k0[i] = v[i];
+        for (int u = 0; u < U; ++u) Act<T>::load(base + (long)min(rb + u * RL, nrows - 1) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rb + u * RL >= nrows) break;
+            if (cnt == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) k0[i] = v[u][i];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { const float d = v[u][i] - k0[i]; s[i] += d; ss[i] += d * d; }
+            ++cnt;
         }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { const float d = v[i] - k0[i]; s[i] += d; ss[i] += d * d; }
-        ++cnt;
     }
     const float n = (float)cnt;
     sn[threadIdx.x] = n;
@@ -281,18 +289,26 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* dy, const
         istd[i] = save_invstd[(long)g * C + cvi * VEC + i];
         s1[i] = 0.f; s2[i] = 0.f;
     }
-    for (int r = rl; r < nrows; r += RL) {
-        float gv[VEC], yv[VEC], xv[VEC];
-        const long o = off0 + (long)r * C;
-        Act<T>::load(dy + o, gv);
-        Act<T>::load(x + o, xv);
-        if (relu) Act<T>::load(y + o, yv);
+    constexpr int U = 4;                               // rows per trip, loads issued together (see norm_stats_kernel)
+    for (int rb = rl; rb < nrows; rb += RL * U) {
+        float gv[U][VEC], yv[U][VEC], xv[U][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            float gm = gv[i];
-            if (relu && !(yv[i] > 0.f)) gm = 0.f;
-            s1[i] += gm;
-            s2[i] += gm * (xv[i] - mean[i]) * istd[i];
+        for (int u = 0; u < U; ++u) {
+            const long o = off0 + (long)min(rb + u * RL, nrows - 1) * C;
+            Act<T>::load(dy + o, gv[u]);
+            Act<T>::load(x + o, xv[u]);
+            if (relu) Act<T>::load(y + o, yv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rb + u * RL >= nrows) break;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float gm = gv[u][i];
+                if (relu && !(yv[u][i] > 0.f)) gm = 0.f;
+                s1[i] += gm;
+                s2[i] += gm * (xv[u][i] - mean[i]) * istd[i];
+            }
         }
     }
 #pragma unroll
