@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="activation / MFMA input type (accumulation, statistics, losses, optimiser are fp32 either way)")
     ap.add_argument("--images", type=int, default=50000)
+    ap.add_argument("--image-size", type=int, default=32, choices=[32, 64],
+                    help="32: CIFAR-10 shape (the headline workload); 64: Tiny-ImageNet shape (200 classes, plain class embedding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (clean per-kernel timings)")
@@ -70,23 +72,27 @@ def max_over_ranks(t, world):
     return t
 
 
-def cpu_baseline(n_images, stage=1):
+def model_kwargs(S):
+    return {} if S == 32 else dict(image_size=S, spatial_emb=False, num_classes=200)
+
+
+def cpu_baseline(n_images, stage=1, S=32):
     """The CPU oracle (stock fp32 torch ops restating the reference) purifying a bounded sample."""
     from oracle import dvae_oracle as O
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    cfg = O.DVAEConfig()
+    cfg = O.DVAEConfig(**model_kwargs(S))
     p = O.recipe_params(cfg)
     g = torch.Generator().manual_seed(0)
-    data = torch.randint(0, 256, (n_images, 32, 32, 3), generator=g, dtype=torch.uint8).numpy()
-    labels = (torch.arange(n_images) % 10).numpy()
-    eps = lambda ps, lo, hi: torch.randn(hi - lo, 256, 16, 16, generator=g)   # noqa: E731
+    data = torch.randint(0, 256, (n_images, S, S, 3), generator=g, dtype=torch.uint8).numpy()
+    labels = (torch.arange(n_images) % cfg.num_classes).numpy()
+    eps = lambda ps, lo, hi: torch.randn(hi - lo, 256, S // 2, S // 2, generator=g)   # noqa: E731
     O.purify(p, cfg, data[:128], labels[:128], eps, stage, batch=128)          # warm-up
     t0 = time.perf_counter()
     O.purify(p, cfg, data, labels, eps, stage, batch=128)
     dt = time.perf_counter() - t0
     return {"value": n_images / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n_images} synthetic 32x32x3 images, stage-1 purification (2 forwards), batch 128, fp32 torch CPU"}
+            "sample": f"{n_images} synthetic {S}x{S}x3 images, stage-1 purification (2 forwards), batch 128, fp32 torch CPU"}
 
 
 def main():
@@ -98,7 +104,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dtype = L.F32 if a.dtype == "f32" else L.BF16
-    cfg = DVAEConfig()
+    S = a.image_size
+    cfg = DVAEConfig(**model_kwargs(S))
+    px = (S * S) // 1024                # work per image relative to 32x32 (every layer scales with the pixel count)
     torch.manual_seed(0)
 
     # ---------------- purification: images resident in HBM, sharded by index -------------------
@@ -109,10 +117,10 @@ def main():
         eng._overlap = False
     n_local = max(Bp, (a.images + world - 1) // world)
     g = torch.Generator(device="cuda").manual_seed(rank)
-    data = torch.randint(0, 256, (n_local, 32, 32, 3), generator=g, dtype=torch.uint8, device="cuda")
-    labels = (torch.arange(n_local, device="cuda") % 10).long()
+    data = torch.randint(0, 256, (n_local, S, S, 3), generator=g, dtype=torch.uint8, device="cuda")
+    labels = (torch.arange(n_local, device="cuda") % cfg.num_classes).long()
     out = torch.empty_like(data)
-    noise = torch.empty(n_local, 3, 32, 32, device="cuda")
+    noise = torch.empty(n_local, 3, S, S, device="cuda")
     nb = n_local // Bp
 
     def purify_step(i):
@@ -148,7 +156,7 @@ def main():
     # one all-gather of the purified shards (once per pass, outside the per-batch hot loop)
     allgather_ms = None
     if world > 1:
-        gathered = torch.empty(world * n_local, 32, 32, 3, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(world * n_local, S, S, 3, dtype=torch.uint8, device="cuda")
         barrier(world)
         t1 = time.perf_counter()
         dist.all_gather_into_tensor(gathered, out)
@@ -187,16 +195,16 @@ def main():
             dist.destroy_process_group()
         return
     peak = PEAK_TFLOPS[a.dtype]
-    probe_tflops = 2.0 * CONV_PROBE_MACS * Bp / (probe_avg * 1e-3) / 1e12
+    probe_tflops = 2.0 * CONV_PROBE_MACS * px * Bp / (probe_avg * 1e-3) / 1e12
     # Roofline of the dominant kernel, the 3x3 64->64 conv at 32x32.  Algorithmic work per image: 2 * 37 748 736
     # FLOP and (read x + write y) = 2 * 64 ch * 1024 px * element size bytes.  fp32: 144 FLOP/B against a ridge of
     # 157.3 T / 8 T = 20 -> MFMA-bound.  bf16: 288 FLOP/B against a ridge of 2500 / 8 = 312 -> HBM-bound (just).
     esz = 4 if a.dtype == "f32" else 2
-    probe_bytes = 2.0 * 64 * 1024 * esz * Bp
+    probe_bytes = 2.0 * 64 * 1024 * px * esz * Bp
     probe_gbs = probe_bytes / (probe_avg * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{a.dtype}.json")
-    if os.path.exists(tpath) and Bp == 1024:
+    if os.path.exists(tpath) and Bp == 1024 and S == 32:
         traffic = json.load(open(tpath)).get("hbm_bytes")     # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch
     kname = "conv_halo_bf16_kernel<64,64,32>" if a.dtype == "bf16" else "igemm_kernel<float,2,1,2,2>"
     if a.dtype == "bf16":
@@ -205,25 +213,26 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": probe_tflops, "peak": peak, "unit": "TFLOP/s", "frac": probe_tflops / peak,
                 "hbm_gbs": probe_gbs}
-    roof.update(kernel=f"{kname} ({CONV_PROBE}: 3x3 conv 64->64 @32x32, {Bp} images/launch)", avg_launch_ms=probe_avg,
+    roof.update(kernel=f"{kname} ({CONV_PROBE}: 3x3 conv 64->64 @{S}x{S}, {Bp} images/launch)", avg_launch_ms=probe_avg,
                 launches_timed=len(probe_ms), algorithmic_bytes_per_launch=probe_bytes,
-                algorithmic_flops_per_launch=2.0 * CONV_PROBE_MACS * Bp, traffic=traffic)
+                algorithmic_flops_per_launch=2.0 * CONV_PROBE_MACS * px * Bp, traffic=traffic)
     res = {
-        "metric": "purified images/sec (node) + VAE train imgs/sec, CIFAR-10 shape",
+        "metric": "purified images/sec (node) + VAE train imgs/sec, " + ("CIFAR-10 shape" if S == 32 else f"{S}x{S} Tiny-ImageNet shape"),
         "value": purify_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / steps_p * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic uint8 CIFAR-shape images resident in HBM, random-init weights",
-        "config": {"workload": "CIFAR-10 shape 32x32x3, ResNet18DVAE(seb=7, latent=256), stage-1 purification "
+        "dtype": a.dtype, "data": f"synthetic uint8 {S}x{S}x3 images resident in HBM, random-init weights",
+        "config": {"workload": ("CIFAR-10 shape 32x32x3" if S == 32 else f"Tiny-ImageNet shape {S}x{S}x3, 200 classes") +
+                               ", ResNet18DVAE(seb=7, latent=256), stage-1 purification "
                                f"(2 eval forwards + clamp + uint8 quantise), {Bp} images/GPU/step, sharded by image index",
                    "purify_batch_per_gpu": Bp, "train_batch_per_gpu": a.train_batch, "images_per_gpu": n_local},
         "train_images_per_sec": train_ips, "train_ms_per_step": train_ms, "allgather_ms": allgather_ms,
         "purify_images_per_sec_skipping_unread_decoder": lean_ips,
-        "purify_tflops": 2.0 * 2 * FWD_MACS * purify_ips / 1e12,
-        "train_tflops": (2.0 * TRAIN_MACS * train_ips / 1e12) if train_ips else None,
+        "purify_tflops": 2.0 * 2 * FWD_MACS * px * purify_ips / 1e12,
+        "train_tflops": (2.0 * TRAIN_MACS * px * train_ips / 1e12) if train_ips else None,
         "roofline": roof,
     }
     if not a.no_cpu_baseline and world == 1:
-        res["cpu_baseline"] = cpu_baseline(1024)
+        res["cpu_baseline"] = cpu_baseline(1024 // px, S=S)
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

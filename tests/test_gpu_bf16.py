@@ -38,6 +38,7 @@ CONVS = [
     (64, 64, 3, 1, 1, False, 16, False),      # LDS-halo kernel with 16-wide tiles
     (32, 64, 3, 1, 1, False, 64, False),      # 64x64 images: two tiles per row
     (64, 64, 3, 1, 1, True, 32, True),
+    (64, 64, 3, 1, 1, False, 64, False),      # 64x64 images: all-tap weight gradient with two tiles per row
 ]
 
 
@@ -341,3 +342,29 @@ def test_instance_norm_per_image_kernels_bf16(B, hw, c):
     ya.zero_(); dxa.zero_()
     run(2)                                   # the first two images alone
     assert torch.equal(ya[:2], y_all[:2]) and torch.equal(dxa[:2], dx_all[:2])
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_model_forward_bf16_64x64(train):
+    """Tiny-ImageNet shape (64x64, 200 classes, plain class embedding): the tile loops see two tiles per row, the
+    per-image InstanceNorm kernels and the image-resident conv do not apply and the generic kernels take over."""
+    kw = dict(image_size=64, spatial_emb=False, num_classes=200)
+    ocfg, cfg = O.DVAEConfig(**kw), DVAEConfig(**kw)
+    eng = DVAEEngine(cfg, 2, "cuda", L.BF16)
+    p = O.recipe_params(ocfg)
+    eng.load_params(p)
+    x, y, eps = O.make_inputs(ocfg, 2)
+    with torch.no_grad():
+        ref = O.forward(p, ocfg, x, y, eps, train, {})
+    x0 = eng.input_from_nchw(x.cuda())
+    e = eng.eps_from_nchw(eps.cuda())
+    rec_pre, pp = eng.forward(x0, y.cuda(), e, 2, train)
+    rec = eng.loss_sums()
+    assert l2_err(from_act(rec[:2], 3), ref["rec"]) < 3e-2
+    assert l2_err(from_act(pp[:2], 3), ref["perturbation"]) < 6e-2
+    if train:
+        eng.loss_gate(11, 3.0, 0.01)
+        eng.backward()
+        eng.adam_step()
+        torch.cuda.synchronize()
+        assert np.isfinite(float(eng.scal[L.SCAL["grad_norm"]]))
