@@ -100,9 +100,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # DVAE_BENCH_BACKEND=gloo rehearses the multi-rank code path with every rank on the GPUs that are there
+    # (ranks share a card; RCCL wants one card per rank); the numbers of such a run mean nothing
+    backend = os.environ.get("DVAE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dtype = L.F32 if a.dtype == "f32" else L.BF16
     S = a.image_size
     cfg = DVAEConfig(**model_kwargs(S))
