@@ -15,8 +15,11 @@ def probe_values(path, counter, images):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     vals, name = [], None
+    # bf16 runs: the bracketed launch is a conv_halo kernel (the fused encoder head has conv1's total grid size too,
+    # and is followed by a gather GEMM); fp32 runs have no conv_halo launches and no fused head
+    halo_run = any("conv_halo" in r["Kernel_Name"] for r in rows)
     for prev, cur in zip(rows, rows[1:]):
-        conv = "conv_halo" in cur["Kernel_Name"] or "igemm_kernel" in cur["Kernel_Name"]
+        conv = "conv_halo" in cur["Kernel_Name"] if halo_run else "igemm_kernel" in cur["Kernel_Name"]
         if conv and "igemm_kernel" in prev["Kernel_Name"] and int(prev["Grid_Size"]) == 2048 * images:
             vals.append(float(cur["Counter_Value"]))
             name = cur["Kernel_Name"]
