@@ -694,6 +694,7 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
         if (g > 128) g = 128;
         if (g < 1) g = 1;
         W.halo_per = (W.halo_tiles + g - 1) / g;
+        W.halo_per += W.halo_per & 1;                  // the kernel walks its tiles two at a time
         W.S = (W.halo_tiles + W.halo_per - 1) / W.halo_per;
     }
     return DVAE_OK;

@@ -7,9 +7,13 @@
 // takes all nine taps out of that copy -- a tap is just another start row in the halo.  The four waves split the
 // 64 x 64 output of a tap into 32 x 32 quadrants; each keeps its quadrant of all nine taps in 144 accumulator
 // registers for its whole run of tiles, so the only output is one [576][64] fp32 slab per workgroup, in the layout
-// wgrad_reduce_kernel sums.  LDS is double-buffered: the next tile's rows are fetched into registers before the MFMA
-// loop of the current tile and written to the other buffer after it, one barrier per tile.
+// wgrad_reduce_kernel sums.  LDS is double-buffered and the registers run two tiles ahead: a tile's rows are fetched
+// into one of two register sets before the MFMA loop of the tile two before it (one loop, 1.1 us, is shorter than a
+// memory round trip under load) and written to the idle LDS buffer after the loop of the tile before it; one barrier
+// per tile.
 #pragma once
+#include <type_traits>
+
 #include "igemm.hpp"
 
 namespace dvae {
@@ -30,7 +34,9 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
     const int c8 = tid & 7, p0 = tid >> 3;              // this thread stages vector c8 of pixels p0 + 32 k
-    const int t0 = blockIdx.x * a.per, t1 = min(a.ntiles, t0 + a.per);
+    // `per` is even: the tile loop is unrolled by two (one copy per register set) without a branch between the copies;
+    // slots past the last tile are staged as zeros and add nothing
+    const int t0 = blockIdx.x * a.per, t1 = t0 + a.per;
 
     f32x16 acc[9];
 #pragma unroll
@@ -39,8 +45,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    u32x4 hreg[7], dreg[4];
-    auto issue = [&](int t) {
+    u32x4 hregs[2][7], dregs[2][4];                     // register set s holds tile t0 + s (mod 2)
+    auto issue = [&](int t, auto setc) {
+        constexpr int SET = decltype(setc)::value;
+        u32x4 (&hreg)[7] = hregs[SET];
+        u32x4 (&dreg)[4] = dregs[SET];
+        const bool live = t < a.ntiles;
         const int tx = t % a.tiles_x, r = t / a.tiles_x, ty = r % a.tiles_y, b = r / a.tiles_y;
         const int y0 = ty * 4, x0 = tx * 32;
         const bf16* xb = a.xg + (long)b * a.H * a.W * 64 + c8 * 8;
@@ -51,21 +61,26 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
             const int hy = hp / 34, hx = hp - hy * 34;
             const int iy = y0 + hy - 1, ix = x0 + hx - 1;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (hp < WH_HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            if (live && hp < WH_HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 v = *reinterpret_cast<const u32x4*>(xb + (iy * a.W + ix) * 64);
             hreg[k] = v;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = p0 + 32 * k;
-            dreg[k] = *reinterpret_cast<const u32x4*>(db + ((y0 + (p >> 5)) * a.W + x0 + (p & 31)) * 64);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (live) v = *reinterpret_cast<const u32x4*>(db + ((y0 + (p >> 5)) * a.W + x0 + (p & 31)) * 64);
+            dreg[k] = v;
         }
     };
     auto colsum = [&](const u32x4& v) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bs[2 * c] += __uint_as_float(v[c] << 16); bs[2 * c + 1] += __uint_as_float(v[c] & 0xffff0000u); }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](auto bufc, auto setc) {
+        constexpr int buf = decltype(bufc)::value, SET = decltype(setc)::value;
+        const u32x4 (&hreg)[7] = hregs[SET];
+        const u32x4 (&dreg)[4] = dregs[SET];
         unsigned char* xh = smem + buf * WH_BUF;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -85,15 +100,11 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
         }
     };
 
-    if (t0 < t1) {
-        issue(t0);
-        stash(0);
-    }
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) & 1;
-        const bool more = t + 1 < t1;
-        if (more) issue(t + 1);
+    // one tile: fetch tile t + 2 into the register set tile t came from, MFMAs on LDS buffer `buf`, then tile t + 1
+    // (the other register set, fetched a tile ago) goes to the other buffer
+    auto tile_step = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;     // LDS buffer and register set of tile t; the other ones hold tile t + 1
+        if (t + 2 < t1) issue(t + 2, bufc);
         const unsigned char* xh = smem + buf * WH_BUF;
         const unsigned char* dt = xh + WH_XB;
         // One wave per SIMD: nothing else hides the LDS latency, so the fragment reads are pipelined by hand.  The
@@ -126,8 +137,19 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stash(buf ^ 1);
+        if (t + 1 < t1) stash(std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
+    };
+
+    if (t0 < t1) {
+        issue(t0, std::integral_constant<int, 0>{});
+        issue(t0 + 1, std::integral_constant<int, 1>{});
+        stash(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; t += 2) {
+        tile_step(t, std::integral_constant<int, 0>{});
+        tile_step(t + 1, std::integral_constant<int, 1>{});
     }
 
     const int r = lane & 31, h = lane >> 5;
