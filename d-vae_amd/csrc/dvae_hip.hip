@@ -6,6 +6,7 @@
 #include "conv_halo.hpp"
 #include "conv_image.hpp"
 #include "wgrad_halo.hpp"
+#include "conv_stem.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -138,6 +139,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation / output statistics unavailable for this launch");
     if (try_launch_image_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
         DVAE_CHECK_LAUNCH("conv_image");
+        return DVAE_OK;
+    }
+    if (try_launch_stem_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_stem");
         return DVAE_OK;
     }
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
