@@ -7,8 +7,8 @@
 //
 // Persistent 256-thread workgroups walk 8 x 32 pixel tiles: halo (10 x 34 pixels, 5.4 KB) to LDS, 20 MFMAs per wave
 // (64 pixels x 64 channels), epilogue (scale / shift / ReLU: the folded BatchNorm of the eval path) into the wave's LDS
-// patch, whole 128-byte pixel rows to HBM.  Two workgroups share a CU (54 KB of LDS each) and hide each other's
-// load and store latency; there is no software pipeline inside a workgroup.
+// patch, whole 128-byte pixel rows to HBM.  Four workgroups share a CU (36 KB of LDS each) and hide each other's
+// store latency; the next tile's halo is fetched into registers under the current tile's MFMAs and stores.
 #pragma once
 #include "igemm.hpp"
 
@@ -32,7 +32,7 @@ constexpr int ST_SRS = 64 * 2 + 16;                    // patch row: 64 channels
 __global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char halo[ST_HP * 16];
     __shared__ __attribute__((aligned(16))) unsigned char wlds[64 * ST_WR];
-    __shared__ __attribute__((aligned(16))) unsigned char patch[4 * 64 * ST_SRS];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[4 * 32 * ST_SRS];
     __shared__ __attribute__((aligned(16))) float ssl[128];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
 
@@ -57,24 +57,33 @@ __global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const StemArgs a) {
     // wave w owns tile rows 2w, 2w + 1: pixel block p (0, 1) is row 2w + p, lane r its column
     const unsigned char* hrow = halo + ((2 * wave + 1) * ST_HW + r + 1) * 16;
     const unsigned char* wrow = wlds + r * ST_WR + h * 16;
-    unsigned char* stg = patch + wave * (64 * ST_SRS);
+    unsigned char* stg = patch + wave * (32 * ST_SRS);
     const int sp = lane >> 3, sc8 = lane & 7;              // coalesced side: 8 pixels x 8 sixteen-byte chunks per instruction
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    u32x4 hv[2];
+    auto fetch = [&](int tile) {                           // this thread's two halo pixels of `tile` -> registers
         const int tx = tile % a.tiles_x, q = tile / a.tiles_x, ty = q % a.tiles_y, b = q / a.tiles_y;
-        const int y0 = ty * 8, x0 = tx * 32;
         const bf16* ib = a.in + (long)b * a.H * a.W * 8;
-        u32x4 hv[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int hp = tid + 256 * k;
             const int hy = hp / ST_HW, hx = hp - hy * ST_HW;
-            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+            const int iy = ty * 8 + hy - 1, ix = tx * 32 + hx - 1;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (hp < ST_HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 v = *reinterpret_cast<const u32x4*>(ib + (iy * a.W + ix) * 8);
             hv[k] = v;
         }
+    };
+    auto wave_lds_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x, q = tile / a.tiles_x, ty = q % a.tiles_y, b = q / a.tiles_y;
+        const int y0 = ty * 8, x0 = tx * 32;
         __syncthreads();                                   // the previous tile's halo has been read by every wave
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const StemArgs a) {
             if (hp < ST_HP) *reinterpret_cast<u32x4*>(halo + hp * 16) = hv[k];
         }
         __syncthreads();                                   // halo (and, first time, weights and scale / shift) visible
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);   // in flight under this tile's MFMAs and stores
 
         f32x16 acc[2][2];                                  // [pixel block][channel block]
 #pragma unroll
@@ -104,9 +114,10 @@ __global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const StemArgs a) {
                     // D[i = out channel][j = pixel]: a lane ends up with 4 consecutive channels per register quad
                     acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[j], pv[p], acc[p][j], 0, 0, 0);
         }
-        // epilogue: lane (pixel r of block p, quad g of channel block j) -> the wave's patch [64 pixels][64 channels]
+        // epilogue, one 32-pixel row at a time: lane (pixel r, quad g of channel block j) -> the wave's patch
+        // [32 pixels][64 channels] -> whole 128-byte pixel rows (8 pixels per store instruction)
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2; ++p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -121,21 +132,18 @@ __global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const StemArgs a) {
                         if (a.relu) v = fmaxf(v, 0.f);
                         o[k] = (bf16)v;
                     }
-                    *reinterpret_cast<bf16x4*>(stg + (p * 32 + r) * ST_SRS + nl * 2) = o;
+                    *reinterpret_cast<bf16x4*>(stg + r * ST_SRS + nl * 2) = o;
                 }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        bf16* ob = a.out + ((long)(b * a.H + y0 + 2 * wave) * a.W + x0) * 64;
+            wave_lds_fence();
+            bf16* ob = a.out + ((long)(b * a.H + y0 + 2 * wave + p) * a.W + x0) * 64;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {                      // 8 pixels per instruction: 64 pixels = 2 rows of 32
-            const int px = i * 8 + sp;                     // pixel of the wave's 64: row px >> 5, column px & 31
-            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * ST_SRS + sc8 * 16);
-            *reinterpret_cast<u32x4*>(ob + ((px >> 5) * a.W + (px & 31)) * 64 + sc8 * 8) = v;
+            for (int i = 0; i < 4; ++i) {
+                const int px = i * 8 + sp;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * ST_SRS + sc8 * 16);
+                *reinterpret_cast<u32x4*>(ob + px * 64 + sc8 * 8) = v;
+            }
+            wave_lds_fence();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -159,7 +167,7 @@ static bool try_launch_stem_bf16(const GemmPlan& P, const void* in, const void* 
     a.H = P.Hout; a.W = P.Wout; a.tiles_x = P.Wout / 32; a.tiles_y = P.Hout / 8;
     a.ntiles = P.B * a.tiles_x * a.tiles_y; a.Ktot = P.Ktot;
     memcpy(a.dy, P.ph[0].dy, 16); memcpy(a.dx, P.ph[0].dx, 16);
-    const int grid = a.ntiles < 512 ? a.ntiles : 512;      // two workgroups per CU (54 KB of LDS each)
+    const int grid = a.ntiles < 1024 ? a.ntiles : 1024;    // four workgroups per CU (36 KB of LDS each)
     hipLaunchKernelGGL(conv_stem_bf16_kernel, dim3(grid), dim3(256), 0, st, a);
     return true;
 }
