@@ -444,8 +444,10 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     a.lx = ilog2_exact(P.Wout / TW); a.ly = ilog2_exact(P.Hout / (256 / TW));
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
     const int ntiles = P.B << (a.lx + a.ly);
-    // one persistent workgroup per CU (its LDS footprint allows no more); tiles are strided over the grid
-    dim3 grid(ntiles < 256 ? ntiles : 256, P.Npad / NT), block(512);
+    // persistent workgroups, tiles strided over the grid: one per CU where the LDS footprint allows no more, two for the
+    // small shapes (32 -> 32 channels: 66 KB), whose tiles are mostly serial latency that a second workgroup hides
+    const int per_cu = 2 * halo_lds_bytes_of(P.CgS, NT, TW) <= HALO_LDS_MAX ? 2 : 1;
+    dim3 grid(ntiles < 256 * per_cu ? ntiles : 256 * per_cu, P.Npad / NT), block(512);
     const bool f_in = in_ss != nullptr, f_st = stats != nullptr;
 #define HALO_CASE(C, N, T, FI, FS)                                                                           \
     if (P.CgS == C && NT == N && TW == T && f_in == FI && f_st == FS) {                                      \
