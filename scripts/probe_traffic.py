@@ -2,7 +2,8 @@
 
 usage: python scripts/probe_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [images_per_launch]
 
-The bracketed launch is the conv dispatch right after conv1 (the gather GEMM launched with 2048 * images threads).
+The bracketed launch is the conv dispatch right after conv1 (bf16: the conv_stem kernel; fp32: the gather GEMM launched
+with 2048 * images threads).
 FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64
 bytes, so it is doubled before being compared with a byte count; WRITE_SIZE is exact for 16-byte-per-lane stores.
 """
@@ -20,7 +21,9 @@ def probe_values(path, counter, images):
     halo_run = any("conv_halo" in r["Kernel_Name"] for r in rows)
     for prev, cur in zip(rows, rows[1:]):
         conv = "conv_halo" in cur["Kernel_Name"] if halo_run else "igemm_kernel" in cur["Kernel_Name"]
-        if conv and "igemm_kernel" in prev["Kernel_Name"] and int(prev["Grid_Size"]) == 2048 * images:
+        first = "conv_stem" in prev["Kernel_Name"] if halo_run else ("igemm_kernel" in prev["Kernel_Name"] and
+                                                                      int(prev["Grid_Size"]) == 2048 * images)
+        if conv and first:
             vals.append(float(cur["Counter_Value"]))
             name = cur["Kernel_Name"]
     return vals, name
