@@ -32,12 +32,17 @@ struct ImageConvArgs {
     // vector load and a wait on every outstanding load each time
     int slab_toff[16], slab_k0[16], slab_phase[16];
     int phase_d0y[4], phase_d0x[4];
+    // fused encoder head (ZF kernels): `in` is the stem output, the weight rows are [mu | log_var] of a 1x1 conv with
+    // 2 * zL outputs, `shift` its 2 * zL biases; slab q computes mu and log_var of latent channels [32 q, 32 q + 32) and
+    // the epilogue writes z = eps * exp(log_var / 2) + mu (bf16, [B][256][zL]) with eps drawn in place
+    int zL;
+    PhiloxKey zkey;
 };
 
 // NSLAB (phase, tap) slabs per image; bit q of LASTMASK: slab q is the last tap of its phase.  Both are compile-time so
 // that an image is one straight-line block: with the register ring, the halo prefetch and the drain stores all in
 // flight at once, the wait counts the compiler derives are exact only if no branch separates a load from its use.
-template <int CIN, int NT, int NSLAB, unsigned LASTMASK>
+template <int CIN, int NT, int NSLAB, unsigned LASTMASK, bool ZF = false>
 __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArgs a) {
     constexpr int S = 16, HWD = S + 2, HP = HWD * HWD;    // input image side; halo side; halo pixels
     constexpr int RS = CIN * 2 + 16;                      // bytes per staged pixel / weight row (16-byte pad spreads banks)
@@ -46,7 +51,10 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     constexpr int TN = NT / 32, KS = CIN / 16;
     constexpr int HV = (HP * VPP + 511) / 512;            // halo vectors per thread
     constexpr int WV = NT * VPP / 512;                    // weight-slab vectors per thread
-    constexpr int SRS = NT * 2 + 16, VPS = NT / 8, PPI = 64 / VPS, NI = 32 / PPI;
+    constexpr int OC = ZF ? NT / 2 : NT;                  // channels a finished slab group leaves in the patch
+    constexpr int SSLN = ZF ? 16 * NSLAB * 4 : NT;        // biases kept in LDS (ZF: all 2 * zL = 64 * NSLAB of them)
+    constexpr int SRS = OC * 2 + 16, VPS = OC / 8, PPI = 64 / VPS, NI = 32 / PPI;
+    static_assert(!ZF || LASTMASK == (1u << NSLAB) - 1u, "fused head: every slab is a finished block of channels");
     constexpr int RING = (NSLAB % 4 == 0) ? 4 : 3;        // slabs in flight in registers; divides NSLAB: static slots
     static_assert(NSLAB % RING == 0, "ring slots must be static per slab");
     static_assert(NT * VPP % 512 == 0 && NI + 1 <= KS && HV <= 2 * KS && NSLAB >= 2, "slab split / drain and prefetch slots");
@@ -55,15 +63,19 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     unsigned char* halo = smem;                                     // [HP][RS]
     unsigned char* wbuf = smem + HALO_BYTES;                        // [2][NT][RS]
     float* ssl = reinterpret_cast<float*>(smem + HALO_BYTES + 2 * WBUF);   // shift[NT]
-    int* tab = reinterpret_cast<int*>(smem + HALO_BYTES + 2 * WBUF + NT * 4 + 8 * 32 * SRS);   // [16][4] slabs, then [4][2] phases
+    int* tab = reinterpret_cast<int*>(smem + HALO_BYTES + 2 * WBUF + SSLN * 4 + 8 * 32 * SRS);   // [16][4] slabs, then [4][2] phases
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    unsigned char* stg = smem + HALO_BYTES + 2 * WBUF + NT * 4 + wave * (32 * SRS);
+    unsigned char* stg = smem + HALO_BYTES + 2 * WBUF + SSLN * 4 + wave * (32 * SRS);
 
     const bf16* in = reinterpret_cast<const bf16*>(a.in);
     const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
     bf16* outb = reinterpret_cast<bf16*>(a.out);
-    if (tid < NT) ssl[tid] = (tid < a.N && a.shift) ? a.shift[tid] : 0.f;
+    if (ZF) {
+        if (tid < SSLN) ssl[tid] = a.shift ? a.shift[tid] : 0.f;
+    } else if (tid < NT) {
+        ssl[tid] = (tid < a.N && a.shift) ? a.shift[tid] : 0.f;
+    }
     if (tid < 16) { tab[tid * 4 + 0] = a.slab_toff[tid] * RS; tab[tid * 4 + 1] = a.slab_k0[tid]; }
     if (tid < 4) { tab[64 + tid * 2] = a.phase_d0y[tid]; tab[64 + tid * 2 + 1] = a.phase_d0x[tid]; }
     __syncthreads();
@@ -71,14 +83,21 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     // ---- halo: HV vectors per thread, border pixels (outside the image) are zeros ----
     u32x4 hreg[HV];
     auto halo_pos = [&](int k, int& hp, int& cv) { const int v = tid + 512 * k; hp = v / VPP; cv = v % VPP; };
-    auto load_halo_vec = [&](int b, int k) {
+    // byte offset of halo vector k inside an image (32 bits: the image base is uniform and stays in scalar registers)
+    unsigned hofs[HV];
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
         int hp, cv;
         halo_pos(k, hp, cv);
         const int iy = hp / HWD - 1, ix = hp % HWD - 1;
         const bool ok = hp < HP && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
         // border / tail vectors read pixel 0 of the image and are zeroed on the way to LDS: no branch around the load
         const int py = ok ? iy : 0, px = ok ? ix : 0;
-        hreg[k] = *reinterpret_cast<const u32x4*>(in + ((long)(b * S + py) * S + px) * CIN + cv * 8);
+        hofs[k] = (unsigned)((py * S + px) * CIN + cv * 8) * 2u;
+    }
+    auto load_halo_vec = [&](int b, int k) {
+        const unsigned char* ib = reinterpret_cast<const unsigned char*>(in + (long)b * (S * S * CIN));
+        hreg[k] = *reinterpret_cast<const u32x4*>(ib + hofs[k]);
     };
     auto store_halo = [&]() {
 #pragma unroll
@@ -94,13 +113,23 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     };
     // ---- weight slab q = (phase, tap): NT rows of CIN, WV vectors per thread, ring slot q % RING ----
     u32x4 wreg[RING][WV];
+    // this thread's vectors of a slab: a per-thread byte offset that does not depend on the slab, plus a uniform slab
+    // base (so a slab costs no vector address arithmetic and no address registers of its own)
+    unsigned wofs[WV];
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+        const int v = tid + 512 * k, n = v / VPP, cv = v % VPP;
+        // fused head: rows 0..31 of a slab are mu of 32 channels, rows 32..63 the same channels' log_var
+        const int row = ZF ? (n >> 5) * a.zL + (n & 31) : n;
+        wofs[k] = (unsigned)(row * a.Ktot + cv * 8) * 2u;
+    }
     auto load_slab = [&](int slot, int q) {                // slot, q: compile-time at every call site
         const int k0 = __builtin_amdgcn_readfirstlane(tab[q * 4 + 1]);
+        // (read from the LDS table, the slab base is not a loop invariant the compiler could hoist: it would keep a
+        // 64-bit address per slab and vector in registers for the whole kernel)
+        const unsigned char* sbase = reinterpret_cast<const unsigned char*>(wp) + (long)k0 * 2;
 #pragma unroll
-        for (int k = 0; k < WV; ++k) {
-            const int v = tid + 512 * k, n = v / VPP, cv = v % VPP;
-            wreg[slot][k] = *reinterpret_cast<const u32x4*>(wp + (long)n * a.Ktot + k0 + cv * 8);
-        }
+        for (int k = 0; k < WV; ++k) wreg[slot][k] = *reinterpret_cast<const u32x4*>(sbase + wofs[k]);
     };
     auto store_slab = [&](int slot, int buf) {
 #pragma unroll
@@ -115,7 +144,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     const unsigned char* hrow = halo + ((gy + 1) * HWD + gx + 1) * RS + 16 * h;
     const unsigned char* wrow = wbuf + r * RS + 16 * h;
     const int sp = lane / VPS, sc8 = lane % VPS;           // coalesced side: lane = (pixel sp of a PPI group, 8-channel chunk sc8)
-    const bool chunk_live = sc8 * 8 < a.NS;
+    const bool chunk_live = ZF || sc8 * 8 < a.NS;
     // output pixel of this lane's 16-byte piece i, relative to the phase's first pixel; and each phase's first pixel
     // relative to the image (uniform, kept in scalar registers: the drain slots sit between MFMAs and must not wait on LDS)
     int lpix[NI], d0[4];
@@ -128,6 +157,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     for (int p = 0; p < 4; ++p)
         d0[p] = __builtin_amdgcn_readfirstlane(tab[64 + p * 2]) * a.Wout + __builtin_amdgcn_readfirstlane(tab[64 + p * 2 + 1]);
     auto out_off = [&](int b, int p, int i) -> long {      // p, i: compile-time at every call site
+        if (ZF) return ((long)b * (S * S) + lpix[i]) * a.zL + 32 * p + sc8 * 8;
         return ((long)b * (a.Hout * a.Wout) + d0[p] + lpix[i]) * a.NS + sc8 * 8;
     };
     auto wave_lds_fence = [&]() {
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + j * 32 + 8 * g + 4 * h);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + (ZF ? j * a.zL + 32 * q : j * 32) + 8 * g + 4 * h);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[j][4 * g + k] = sh[k];
                     }
@@ -194,15 +224,35 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
                     if (s > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(db, dp, s - 1)) = dreg;
                     if (s < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (s * PPI + sp) * SRS + sc8 * 16);
                 }
-                // the next image's halo, in the image's first two slabs
-                if (q == 0 && s < HV) load_halo_vec(nb, s);
-                if (q == 1 && KS + s < HV) load_halo_vec(nb, KS + s);
+                // the next image's halo: in the image's first two slabs, or (fused head: its epilogue wants the registers,
+                // and its slabs are long enough to cover the round trip) in the last two
+                constexpr int HQ = ZF ? NSLAB - 2 : 0;
+                if (q == HQ && s < HV) load_halo_vec(nb, s);
+                if (q == HQ + 1 && KS + s < HV) load_halo_vec(nb, KS + s);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[s & 1][j], pv[s & 1], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (last_tap) {
+            if (last_tap && ZF) {
+                // ---- mu (acc[0]) and log_var (acc[1]) of 32 latent channels: draw eps, park z in the patch ----
+                const uint64_t img = a.zkey.index ? (uint64_t)a.zkey.index[b] : (uint64_t)(a.zkey.first + b);
+                unsigned e0 = (unsigned)(wave * 32 + r) * (unsigned)a.zL + 32u * q + 4u * h;   // element in the image
+                // the counter does not depend on the image, so the first Philox round of every (slab, quad) is a loop
+                // invariant: hoisted, it would sit in 64 registers for the whole kernel
+                asm volatile("" : "+v"(e0));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 e = philox_normal4(a.zkey, img, (e0 + 8u * g) >> 2);
+                    bf16x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (bf16)(e[k] * __expf(0.5f * acc[1][4 * g + k]) + acc[0][4 * g + k]);
+                    *reinterpret_cast<bf16x4*>(stg + r * SRS + (8 * g + 4 * h) * 2) = o;
+                    __builtin_amdgcn_sched_barrier(0);     // one Philox chain at a time: registers, not latency, are short
+                }
+                wave_lds_fence();
+            }
+            if (last_tap && !ZF) {
                 // ---- the phase is finished: ReLU, bf16, park in the patch (drained inside the next slab) ----
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -236,6 +286,10 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
 template <int CIN, int NT>
 static constexpr int image_lds_bytes() {
     return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + NT * 4 + 8 * 32 * (NT * 2 + 16) + (16 * 4 + 4 * 2) * 4;
+}
+template <int CIN, int NT, int NSLAB>
+static constexpr int image_zf_lds_bytes() {
+    return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + 64 * NSLAB * 4 + 8 * 32 * (NT + 16) + (16 * 4 + 4 * 2) * 4;
 }
 
 // Slab structure of a plan this kernel is built for: a transposed gather over 16x16 phase grids with 128 gathered and
@@ -297,6 +351,43 @@ static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void*
     }
     IMAGE_CASE(16, 0x8888u) IMAGE_CASE(9, 0x115u)
 #undef IMAGE_CASE
+    return false;
+}
+
+// Fused encoder head on the image-resident kernel: 1x1 conv 128 -> 2 L over 16x16 maps, L = 32 * (4 or 8).
+static bool image_zf_applicable(const GemmPlan& P, int L) {
+    if (P.nphase != 1 || P.CgS != 128 || P.Hin != 16 || P.Win != 16 || P.Hout != 16 || P.Wout != 16 || P.N != 2 * L) return false;
+    const Phase& ph = P.ph[0];
+    if (ph.ntaps != 1 || ph.dy[0] || ph.dx[0] || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return false;
+    return L == 128 || L == 256;
+}
+
+static bool try_launch_image_zf(const GemmPlan& P, const void* in, const void* wp, const float* bias, void* z, int L,
+                                const PhiloxKey& key, hipStream_t st) {
+    if (!image_zf_applicable(P, L)) return false;
+    ImageConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.wp = wp; a.out = z; a.shift = bias; a.relu = 0;
+    a.B = P.B; a.Hout = 16; a.Wout = 16; a.N = L; a.NS = L; a.Ktot = P.Ktot;
+    a.nslab = L / 32; a.DS = 1;
+    for (int q = 0; q < 16; ++q) a.slab_k0[q] = P.ph[0].koff + 32 * q * P.Ktot;   // slab q: weight rows 32 q .. of mu and of log_var
+    a.zL = L; a.zkey = key;
+    dim3 grid(P.B < 256 ? P.B : 256), block(512);
+#define IMAGE_ZF_CASE(NS_)                                                                                              \
+    if (a.nslab == NS_) {                                                                                               \
+        constexpr int lds = image_zf_lds_bytes<128, 64, NS_>();                                                         \
+        static_assert(lds <= 160 * 1024, "LDS budget");                                                                 \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, NS_, (1u << NS_) - 1u, true>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                 \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, NS_, (1u << NS_) - 1u, true>), grid, block, lds, st, a);    \
+        return true;                                                                                                    \
+    }
+    IMAGE_ZF_CASE(8) IMAGE_ZF_CASE(4)
+#undef IMAGE_ZF_CASE
     return false;
 }
 

@@ -488,6 +488,10 @@ int dvae_fc_reparam_fwd_philox(const void* x, const void* wp, const float* bias,
     int rc = build_plan(*d, DVAE_OP_FWD, dtype, P);
     if (rc) return rc;
     PhiloxKey key = {index, (long)first, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id};
+    if (try_launch_image_zf(P, x, wp, bias, z, L, key, S(st))) {     // 16x16 maps: the image-resident kernel
+        DVAE_CHECK_LAUNCH("conv_image_zf");
+        return DVAE_OK;
+    }
     return launch_igemm_zf(P, x, wp, bias, z, L, key, S(st));
 }
 
