@@ -36,7 +36,8 @@ __device__ inline f32x4 philox_normal4(const PhiloxKey& k, uint64_t img, uint32_
         // Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sin/v_cos (argument in turns)
         const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
         const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
-        const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+        // sqrt(-2 ln u1): v_sqrt_f32 itself (1 ulp; the argument is in [0, 34), no denormal or range fix-ups needed)
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
         n[2 * h] = rad * __builtin_amdgcn_cosf(u2);
         n[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
