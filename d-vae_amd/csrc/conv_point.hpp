@@ -1,0 +1,144 @@
+// 1x1 unit-stride convolution 256 -> 128 channels in bf16 (post_conv), weights resident in LDS.
+//
+// The gather GEMM treats a 1x1 conv like any other: every 128 x 128 tile re-stages its 64 KB of weights and pays two
+// barriers per 64-deep K slab.  Here a persistent 512-thread workgroup per CU keeps the whole 128 x 256 weight matrix
+// in LDS (66 KB) and streams 128-pixel tiles of the input through a second 66 KB buffer: the next tile's rows are
+// fetched into registers while the current tile's 32 MFMAs per wave run, so a tile costs two barriers for 256 K-deep
+// work.  A wave owns 64 pixels x 32 output channels (two MFMAs per K step share one weight fragment: 1.5 KB of LDS
+// reads per MFMA); results go through the wave's LDS patch and leave as 64-byte channel runs.
+#pragma once
+#include "igemm.hpp"
+
+namespace dvae {
+
+struct PointArgs {
+    const bf16* in;            // [M][256]
+    const bf16* wp;            // packed rows [128][Ktot]
+    bf16* out;                 // [M][128]
+    const float* scale;        // per output channel or NULL (1)
+    const float* shift;        // per output channel or NULL (0)
+    int relu, ntiles, Ktot;    // tiles of 128 pixels
+};
+
+constexpr int PT_CIN = 256, PT_N = 128, PT_RS = PT_CIN * 2 + 16, PT_VPP = PT_CIN / 8;   // padded row; 16-byte vectors per row
+constexpr int PT_SRS = 32 * 2 + 16;                                                     // patch row: 32 channels + pad
+constexpr int PT_LDS = 2 * 128 * PT_RS + 8 * 32 * PT_SRS + 2 * PT_N * 4;
+
+__global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wlds = smem;                          // [128 channels][PT_RS]
+    unsigned char* xlds = smem + 128 * PT_RS;            // [128 pixels][PT_RS]
+    unsigned char* patches = smem + 2 * 128 * PT_RS;
+    float* ssl = reinterpret_cast<float*>(patches + 8 * 32 * PT_SRS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    constexpr int XV = 128 * PT_VPP / 512;               // vectors per thread of a tile (and of the weights)
+
+    for (int v = tid; v < 128 * PT_VPP; v += 512) {
+        const int n = v / PT_VPP, cv = v % PT_VPP;
+        *reinterpret_cast<u32x4*>(wlds + n * PT_RS + cv * 16) = *reinterpret_cast<const u32x4*>(a.wp + (long)n * a.Ktot + cv * 8);
+    }
+    if (tid < PT_N) {
+        ssl[tid] = a.scale ? a.scale[tid] : 1.f;
+        ssl[PT_N + tid] = a.shift ? a.shift[tid] : 0.f;
+    }
+    u32x4 xr[XV];
+    auto fetch = [&](int tile) {                          // a tile is 128 consecutive rows: 64 KB contiguous
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.in + (long)tile * 128 * PT_CIN);
+#pragma unroll
+        for (int k = 0; k < XV; ++k) xr[k] = src[tid + 512 * k];
+    };
+    auto wave_lds_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // wave = (pixel half ph: 64 pixels, channel quarter cq: 32 channels)
+    const int ph = wave >> 2, cq = wave & 3;
+    const unsigned char* xrow = xlds + (ph * 64 + r) * PT_RS + 16 * h;
+    const unsigned char* wrow = wlds + (cq * 32 + r) * PT_RS + 16 * h;
+    unsigned char* stg = patches + wave * (32 * PT_SRS);
+    const int sp = lane >> 2, sc8 = lane & 3;             // coalesced side: 16 pixels x 4 sixteen-byte chunks per instruction
+
+    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                                  // the previous tile has been read by every wave
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int v = tid + 512 * k;
+            *reinterpret_cast<u32x4*>(xlds + (v / PT_VPP) * PT_RS + (v % PT_VPP) * 16) = xr[k];
+        }
+        __syncthreads();                                  // tile (and, first time, weights and scale / shift) visible
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < PT_CIN / 16; ++s) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wrow + 32 * s);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const bf16x8 pv = *reinterpret_cast<const bf16x8*>(xrow + p * 32 * PT_RS + 32 * s);
+                // D[i = out channel][j = pixel]: a lane ends up with 4 consecutive channels per register quad
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, pv, acc[p], 0, 0, 0);
+            }
+        }
+        bf16* ob = a.out + ((long)tile * 128 + ph * 64) * PT_N + cq * 32;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 8 * g + 4 * h;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ssl + cq * 32 + nl);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + PT_N + cq * 32 + nl);
+                bf16x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = acc[p][4 * g + k] * sc[k] + sh[k];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    o[k] = (bf16)v;
+                }
+                *reinterpret_cast<bf16x4*>(stg + r * PT_SRS + nl * 2) = o;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int px = i * 16 + sp;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * PT_SRS + sc8 * 16);
+                *reinterpret_cast<u32x4*>(ob + (long)(p * 32 + px) * PT_N + sc8 * 8) = v;
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+static bool point_applicable(const GemmPlan& P) {
+    if (P.nphase != 1 || P.CgS != PT_CIN || P.N != PT_N || P.NS != PT_N) return false;
+    const Phase& ph = P.ph[0];
+    if (ph.ntaps != 1 || ph.dy[0] || ph.dx[0] || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return false;
+    if (P.Hin != P.Hout || P.Win != P.Wout || ph.Hg != P.Hout || ph.Wg != P.Wout) return false;
+    const long M = (long)P.B * P.Hout * P.Wout;
+    return M % 128 == 0 && M * PT_CIN <= 0x7fffffffL;
+}
+
+static bool try_launch_point_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
+                                  const float* shift, const void* res, int relu, int accumulate, int out_f32,
+                                  hipStream_t st) {
+    if (res || accumulate || out_f32 || !point_applicable(P)) return false;
+    PointArgs a;
+    a.in = (const bf16*)in; a.wp = (const bf16*)wp + P.ph[0].koff; a.out = (bf16*)out; a.scale = scale; a.shift = shift;
+    a.relu = relu; a.ntiles = (int)((long)P.B * P.Hout * P.Wout / 128); a.Ktot = P.Ktot;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_point_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PT_LDS);
+        attr_set = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    hipLaunchKernelGGL(conv_point_bf16_kernel, dim3(grid), dim3(512), PT_LDS, st, a);
+    return true;
+}
+
+}  // namespace dvae

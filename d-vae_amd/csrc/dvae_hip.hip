@@ -7,6 +7,7 @@
 #include "conv_image.hpp"
 #include "wgrad_halo.hpp"
 #include "conv_stem.hpp"
+#include "conv_point.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -143,6 +144,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     }
     if (try_launch_stem_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
         DVAE_CHECK_LAUNCH("conv_stem");
+        return DVAE_OK;
+    }
+    if (try_launch_point_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_point");
         return DVAE_OK;
     }
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));

@@ -39,6 +39,7 @@ CONVS = [
     (32, 64, 3, 1, 1, False, 64, False),      # 64x64 images: two tiles per row
     (64, 64, 3, 1, 1, True, 32, True),
     (64, 64, 3, 1, 1, False, 64, False),      # 64x64 images: all-tap weight gradient with two tiles per row
+    (256, 128, 1, 1, 0, False, 16, True),     # post_conv: weights-resident 1x1 kernel
 ]
 
 
