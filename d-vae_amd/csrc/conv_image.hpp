@@ -24,14 +24,16 @@ struct ImageConvArgs {
     const void* wp;
     void* out;
     const float* shift;      // per-output-channel bias or NULL
+    const float* scale;      // per-output-channel scale or NULL (FULL kernels)
+    const void* res;         // residual, laid out like out, added before the ReLU, or NULL (FULL kernels)
     int relu;
     int B, Hout, Wout, N, NS, Ktot;
     int nslab, DS;           // (phase, tap) slabs per image; output step of a phase grid step
     // per slab: halo offset of the tap (pixels), first K column in the packed rows, phase << 1 | last tap of its phase;
     // per phase: output offset.  Copied to LDS at kernel start: indexing kernel arguments with a run-time index costs a
     // vector load and a wait on every outstanding load each time
-    int slab_toff[16], slab_k0[16], slab_phase[16];
-    int phase_d0y[4], phase_d0x[4];
+    int slab_toff[32], slab_k0[32], slab_phase[32];
+    int phase_d0y[4], phase_d0x[4], phase_n0[4];   // per phase: first output pixel and first output channel
     // fused encoder head (ZF kernels): `in` is the stem output, the weight rows are [mu | log_var] of a 1x1 conv with
     // 2 * zL outputs, `shift` its 2 * zL biases; slab q computes mu and log_var of latent channels [32 q, 32 q + 32) and
     // the epilogue writes z = eps * exp(log_var / 2) + mu (bf16, [B][256][zL]) with eps drawn in place
@@ -42,7 +44,9 @@ struct ImageConvArgs {
 // NSLAB (phase, tap) slabs per image; bit q of LASTMASK: slab q is the last tap of its phase.  Both are compile-time so
 // that an image is one straight-line block: with the register ring, the halo prefetch and the drain stores all in
 // flight at once, the wait counts the compiler derives are exact only if no branch separates a load from its use.
-template <int CIN, int NT, int NSLAB, unsigned LASTMASK, bool ZF = false>
+// FULL: per-channel scale, residual and more than NT output channels (a "phase" is then a block of NT channels of the
+// same pixels): the folded-BatchNorm + shortcut + ReLU epilogue of a residual block's second conv.
+template <int CIN, int NT, int NSLAB, unsigned LASTMASK, bool ZF = false, bool FULL = false>
 __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArgs a) {
     constexpr int S = 16, HWD = S + 2, HP = HWD * HWD;    // input image side; halo side; halo pixels
     constexpr int RS = CIN * 2 + 16;                      // bytes per staged pixel / weight row (16-byte pad spreads banks)
@@ -52,7 +56,8 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     constexpr int HV = (HP * VPP + 511) / 512;            // halo vectors per thread
     constexpr int WV = NT * VPP / 512;                    // weight-slab vectors per thread
     constexpr int OC = ZF ? NT / 2 : NT;                  // channels a finished slab group leaves in the patch
-    constexpr int SSLN = ZF ? 16 * NSLAB * 4 : NT;        // biases kept in LDS (ZF: all 2 * zL = 64 * NSLAB of them)
+    constexpr int SSLN = ZF ? 16 * NSLAB * 4 : (FULL ? 4 * NT : NT);   // biases in LDS (ZF: all 2 zL = 64 NSLAB; FULL: shift | scale of 2 NT)
+    static_assert(!(ZF && FULL), "one epilogue flavour per kernel");
     constexpr int SRS = OC * 2 + 16, VPS = OC / 8, PPI = 64 / VPS, NI = 32 / PPI;
     static_assert(!ZF || LASTMASK == (1u << NSLAB) - 1u, "fused head: every slab is a finished block of channels");
     constexpr int RING = (NSLAB % 4 == 0) ? 4 : 3;        // slabs in flight in registers; divides NSLAB: static slots
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     unsigned char* halo = smem;                                     // [HP][RS]
     unsigned char* wbuf = smem + HALO_BYTES;                        // [2][NT][RS]
     float* ssl = reinterpret_cast<float*>(smem + HALO_BYTES + 2 * WBUF);   // shift[NT]
-    int* tab = reinterpret_cast<int*>(smem + HALO_BYTES + 2 * WBUF + SSLN * 4 + 8 * 32 * SRS);   // [16][4] slabs, then [4][2] phases
+    int* tab = reinterpret_cast<int*>(smem + HALO_BYTES + 2 * WBUF + SSLN * 4 + 8 * 32 * SRS);   // [32][4] slabs, then [4][4] phases
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     unsigned char* stg = smem + HALO_BYTES + 2 * WBUF + SSLN * 4 + wave * (32 * SRS);
@@ -73,11 +78,16 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     bf16* outb = reinterpret_cast<bf16*>(a.out);
     if (ZF) {
         if (tid < SSLN) ssl[tid] = a.shift ? a.shift[tid] : 0.f;
+    } else if (FULL) {
+        if (tid < 2 * NT) {
+            ssl[tid] = (tid < a.N && a.shift) ? a.shift[tid] : 0.f;
+            ssl[2 * NT + tid] = tid < a.N ? (a.scale ? a.scale[tid] : 1.f) : 0.f;
+        }
     } else if (tid < NT) {
         ssl[tid] = (tid < a.N && a.shift) ? a.shift[tid] : 0.f;
     }
-    if (tid < 16) { tab[tid * 4 + 0] = a.slab_toff[tid] * RS; tab[tid * 4 + 1] = a.slab_k0[tid]; }
-    if (tid < 4) { tab[64 + tid * 2] = a.phase_d0y[tid]; tab[64 + tid * 2 + 1] = a.phase_d0x[tid]; }
+    if (tid < 32) { tab[tid * 4 + 0] = a.slab_toff[tid] * RS; tab[tid * 4 + 1] = a.slab_k0[tid]; }
+    if (tid < 4) { tab[128 + tid * 4] = a.phase_d0y[tid]; tab[128 + tid * 4 + 1] = a.phase_d0x[tid]; tab[128 + tid * 4 + 2] = a.phase_n0[tid]; }
     __syncthreads();
 
     // ---- halo: HV vectors per thread, border pixels (outside the image) are zeros ----
@@ -144,22 +154,26 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     const unsigned char* hrow = halo + ((gy + 1) * HWD + gx + 1) * RS + 16 * h;
     const unsigned char* wrow = wbuf + r * RS + 16 * h;
     const int sp = lane / VPS, sc8 = lane % VPS;           // coalesced side: lane = (pixel sp of a PPI group, 8-channel chunk sc8)
-    const bool chunk_live = ZF || sc8 * 8 < a.NS;
+    const bool chunk_live = ZF || FULL || sc8 * 8 < a.NS;
     // output pixel of this lane's 16-byte piece i, relative to the phase's first pixel; and each phase's first pixel
     // relative to the image (uniform, kept in scalar registers: the drain slots sit between MFMAs and must not wait on LDS)
-    int lpix[NI], d0[4];
+    int lpix[NI], d0[4], pn0[4];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int q = i * PPI + sp;                        // pixel of the wave's 32
         lpix[i] = ((2 * wave + (q >> 4)) * a.Wout + (q & 15)) * a.DS;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-        d0[p] = __builtin_amdgcn_readfirstlane(tab[64 + p * 2]) * a.Wout + __builtin_amdgcn_readfirstlane(tab[64 + p * 2 + 1]);
+    for (int p = 0; p < 4; ++p) {
+        d0[p] = __builtin_amdgcn_readfirstlane(tab[128 + p * 4]) * a.Wout + __builtin_amdgcn_readfirstlane(tab[128 + p * 4 + 1]);
+        pn0[p] = FULL ? __builtin_amdgcn_readfirstlane(tab[128 + p * 4 + 2]) : 0;
+    }
     auto out_off = [&](int b, int p, int i) -> long {      // p, i: compile-time at every call site
         if (ZF) return ((long)b * (S * S) + lpix[i]) * a.zL + 32 * p + sc8 * 8;
-        return ((long)b * (a.Hout * a.Wout) + d0[p] + lpix[i]) * a.NS + sc8 * 8;
+        return ((long)b * (a.Hout * a.Wout) + d0[p] + lpix[i]) * a.NS + pn0[p] + sc8 * 8;
     };
+    const bf16* resb = reinterpret_cast<const bf16*>(a.res);
+    u32x4 radd[NI];
     auto wave_lds_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + (ZF ? j * a.zL + 32 * q : j * 32) + 8 * g + 4 * h);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[j][4 * g + k] = sh[k];
+                        for (int k = 0; k < 4; ++k) acc[j][4 * g + k] = FULL ? 0.f : sh[k];   // FULL: scale, then shift, at the end
                     }
             }
             // this slab's ring slot was emptied into LDS a step ago: refill it with the slab RING steps ahead
@@ -223,6 +237,12 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
                 if (s <= NI && (drain_static || (q == 0 && have_prev))) {   // drain slot s of NI + 1: patch -> HBM
                     if (s > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(db, dp, s - 1)) = dreg;
                     if (s < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (s * PPI + sp) * SRS + sc8 * 16);
+                }
+                // the residual rows of a phase, in the second half of its last slab
+                if (FULL && last_tap && s >= KS - NI) {
+                    const int i = s - (KS - NI);
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    radd[i] = a.res ? *reinterpret_cast<const u32x4*>(resb + out_off(b, phase_of(q), i)) : z;
                 }
                 // the next image's halo: in the image's first two slabs, or (fused head: its epilogue wants the registers,
                 // and its slabs are long enough to cover the round trip) in the last two
@@ -251,6 +271,33 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
                     __builtin_amdgcn_sched_barrier(0);     // one Philox chain at a time: registers, not latency, are short
                 }
                 wave_lds_fence();
+            }
+            if (last_tap && FULL) {
+                // ---- scale / shift, then the residual: through the patch (coalesced rows in, register layout out) ----
+                const int n0 = phase_of(q) * NT;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + n0 + j * 32 + 8 * g + 4 * h);
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssl + 2 * NT + n0 + j * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[j][4 * g + k] = acc[j][4 * g + k] * sc[k] + sh[k];
+                    }
+                if (a.res) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16) = radd[i];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const bf16x4 rq = *reinterpret_cast<const bf16x4*>(stg + r * SRS + (j * 32 + 8 * g + 4 * h) * 2);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[j][4 * g + k] += (float)rq[k];
+                        }
+                    wave_lds_fence();
+                }
             }
             if (last_tap && !ZF) {
                 // ---- the phase is finished: ReLU, bf16, park in the patch (drained inside the next slab) ----
@@ -285,11 +332,13 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
 
 template <int CIN, int NT>
 static constexpr int image_lds_bytes() {
-    return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + NT * 4 + 8 * 32 * (NT * 2 + 16) + (16 * 4 + 4 * 2) * 4;
+    return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + NT * 4 + 8 * 32 * (NT * 2 + 16) + (32 * 4 + 4 * 4) * 4;
 }
+template <int CIN, int NT>
+static constexpr int image_full_lds_bytes() { return image_lds_bytes<CIN, NT>() + 3 * NT * 4; }
 template <int CIN, int NT, int NSLAB>
 static constexpr int image_zf_lds_bytes() {
-    return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + 64 * NSLAB * 4 + 8 * 32 * (NT + 16) + (16 * 4 + 4 * 2) * 4;
+    return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + 64 * NSLAB * 4 + 8 * 32 * (NT + 16) + (32 * 4 + 4 * 4) * 4;
 }
 
 // Slab structure of a plan this kernel is built for: a transposed gather over 16x16 phase grids with 128 gathered and
@@ -315,12 +364,56 @@ static ImageGeom image_geom(const GemmPlan& P) {
 }
 static bool image_applicable(const GemmPlan& P) { return image_geom(P).nslab != 0; }
 
+// 3x3 unit-stride conv 128 -> 128 over 16x16 maps (a residual block's convs in layer2): two blocks of 64 output
+// channels x 9 taps = 18 slabs, with the scale / shift / residual / ReLU epilogue.
+static bool image_full_applicable(const GemmPlan& P) {
+    if (P.nphase != 1 || P.CgS != 128 || P.N != 128 || P.NS != 128 || P.Hin != 16 || P.Win != 16 || P.Hout != 16 || P.Wout != 16) return false;
+    const Phase& ph = P.ph[0];
+    if (ph.ntaps != 9 || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X || ph.Hg != 16 || ph.Wg != 16) return false;
+    for (int t = 0; t < 9; ++t)
+        if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return false;
+    return true;
+}
+
+static bool try_launch_image_full(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
+                                  const float* shift, const void* res, int relu, hipStream_t st) {
+    if (!image_full_applicable(P)) return false;
+    ImageConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.wp = wp; a.out = out; a.shift = shift; a.scale = scale; a.res = res; a.relu = relu;
+    a.B = P.B; a.Hout = 16; a.Wout = 16; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    a.nslab = 18; a.DS = 1;
+    const Phase& ph = P.ph[0];
+    for (int half = 0; half < 2; ++half) {
+        a.phase_n0[half] = 64 * half;
+        for (int t = 0; t < 9; ++t) {
+            const int q = half * 9 + t;
+            a.slab_toff[q] = (int)ph.dy[t] * 18 + (int)ph.dx[t];
+            a.slab_k0[q] = ph.koff + t * 128 + 64 * half * P.Ktot;       // weight rows 64 half .. of tap t
+            a.slab_phase[q] = half << 1 | (t == 8 ? 1 : 0);
+        }
+    }
+    constexpr int lds = image_full_lds_bytes<128, 64>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid(P.B < 256 ? P.B : 256), block(512);
+    hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>), grid, block, lds, st, a);
+    return true;
+}
+
 static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                   const float* shift, const void* res, int relu, int accumulate, int out_f32,
                                   hipStream_t st) {
+    if (!accumulate && !out_f32 && try_launch_image_full(P, in, wp, out, scale, shift, res, relu, st)) return true;
     const ImageGeom g = image_geom(P);
     if (scale || res || accumulate || out_f32 || !g.nslab) return false;
     ImageConvArgs a;
+    memset(&a, 0, sizeof(a));
     a.in = in; a.wp = wp; a.out = out; a.shift = shift; a.relu = relu;
     a.B = P.B; a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
     memset(a.slab_toff, 0, sizeof(a.slab_toff)); memset(a.slab_k0, 0, sizeof(a.slab_k0));

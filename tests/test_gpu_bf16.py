@@ -40,6 +40,7 @@ CONVS = [
     (64, 64, 3, 1, 1, True, 32, True),
     (64, 64, 3, 1, 1, False, 64, False),      # 64x64 images: all-tap weight gradient with two tiles per row
     (256, 128, 1, 1, 0, False, 16, True),     # post_conv: weights-resident 1x1 kernel
+    (128, 128, 3, 1, 1, False, 16, False),    # layer2's second conv: image-resident kernel, two blocks of 64 channels
 ]
 
 
@@ -173,12 +174,13 @@ def test_purification_bf16_close_to_fp32_and_shard_invariant(stage):
     assert torch.equal(out3, outs["bf16"][0]) and torch.equal(noise3, outs["bf16"][1])
 
 
-def test_conv_bf16_fused_epilogue_and_accumulate():
-    """scale/shift + residual + ReLU epilogue and the accumulate mode on the LDS-halo kernel."""
+@pytest.mark.parametrize("B,cin,cout,hin", [(3, 64, 64, 32), (5, 128, 128, 16)])
+def test_conv_bf16_fused_epilogue_and_accumulate(B, cin, cout, hin):
+    """scale/shift + residual + ReLU epilogue and the accumulate mode: on the LDS-halo kernel (64 channels at 32x32) and
+    on the image-resident kernel (128 channels at 16x16: layer2's second conv; its accumulate mode is the gather GEMM)."""
     lib = L.lib()
     g = torch.Generator().manual_seed(5)
     q = lambda t: t.bfloat16().float()      # noqa: E731
-    B, cin, cout, hin = 3, 64, 64, 32
     w = q(torch.randn(cout, cin, 3, 3, generator=g) / 24)
     x = q(torch.randn(B, cin, hin, hin, generator=g))
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
