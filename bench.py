@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="activation / MFMA input type (accumulation, statistics, losses, optimiser are fp32 either way)")
     ap.add_argument("--images", type=int, default=50000)
+    ap.add_argument("--stage", type=int, default=1, choices=[0, 1],
+                    help="purification stage: 1 (two forwards, the headline) or 0 (one forward, x - p)")
     ap.add_argument("--image-size", type=int, default=32, choices=[32, 64],
                     help="32: CIFAR-10 shape (the headline workload); 64: Tiny-ImageNet shape (200 classes, plain class embedding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,7 +134,7 @@ def main():
     nb = n_local // Bp
 
     def purify_step(i):
-        eng.purify_batch(data, out, noise, labels, (i % nb) * Bp, Bp, 1)
+        eng.purify_batch(data, out, noise, labels, (i % nb) * Bp, Bp, a.stage)
 
     steps_p = 1 if a.no_purify else a.steps
     for i in range(0 if a.no_purify else a.warmup):
@@ -151,7 +153,7 @@ def main():
     # extra, never `value`: the same pass without the first forward's reconstruction decoder, whose result the
     # reference drops (main_vae_disentangle.py:61-62); outputs are bit-identical (tests/test_gpu_bf16.py)
     lean_ips = None
-    if not a.no_purify:
+    if not a.no_purify and a.stage == 1:
         barrier(world)
         t0 = time.perf_counter()
         for i in range(steps_p):
@@ -230,12 +232,14 @@ def main():
         "ms_per_step": dt / steps_p * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": f"synthetic uint8 {S}x{S}x3 images resident in HBM, random-init weights",
         "config": {"workload": ("CIFAR-10 shape 32x32x3" if S == 32 else f"Tiny-ImageNet shape {S}x{S}x3, 200 classes") +
-                               ", ResNet18DVAE(seb=7, latent=256), stage-1 purification "
-                               f"(2 eval forwards + clamp + uint8 quantise), {Bp} images/GPU/step, sharded by image index",
+                               ", ResNet18DVAE(seb=7, latent=256), " +
+                               ("stage-1 purification (2 eval forwards + clamp + uint8 quantise)" if a.stage == 1 else
+                                "stage-0 purification (1 eval forward + clamp + uint8 quantise)") +
+                               f", {Bp} images/GPU/step, sharded by image index",
                    "purify_batch_per_gpu": Bp, "train_batch_per_gpu": a.train_batch, "images_per_gpu": n_local},
         "train_images_per_sec": train_ips, "train_ms_per_step": train_ms, "allgather_ms": allgather_ms,
         "purify_images_per_sec_skipping_unread_decoder": lean_ips,
-        "purify_tflops": 2.0 * 2 * FWD_MACS * px * purify_ips / 1e12,
+        "purify_tflops": 2.0 * (1 + a.stage) * FWD_MACS * px * purify_ips / 1e12,
         "train_tflops": (2.0 * TRAIN_MACS * px * train_ips / 1e12) if train_ips else None,
         "roofline": roof,
     }
