@@ -684,14 +684,15 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     W.chunk_rows = chunk;
     W.S = (W.M + chunk - 1) / chunk;
     // 3x3 unit-stride 64 -> 64 in bf16: one staged tile serves all nine taps.  Each workgroup leaves a 147 KB slab for
-    // the reduction to read back, so at most one per two CUs, with at least 8 tiles each once there are enough.
+    // the reduction to read back, so at least 8 tiles each once there are enough (batch 128: one workgroup per two
+    // CUs), at most one workgroup per CU.
     bool halo = dtype == DVAE_BF16 && kk == 9 && s == 1 && p == 1 && W.CxS == 64 && W.CdS == 64 && W.Hx == W.Hg && W.Wx == W.Wg &&
                 W.Wg % 32 == 0 && W.Hg % 4 == 0 && (long)W.M * 64 <= 0x7fffffffL;
     if (halo) {
         W.halo = 1;
         W.halo_tiles = d.B * (W.Hg / 4) * (W.Wg / 32);
         int g = W.halo_tiles / 8;
-        if (g > 128) g = 128;
+        if (g > 256) g = 256;
         if (g < 1) g = 1;
         W.halo_per = (W.halo_tiles + g - 1) / g;
         W.halo_per += W.halo_per & 1;                  // the kernel walks its tiles two at a time
