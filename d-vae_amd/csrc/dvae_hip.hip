@@ -434,6 +434,14 @@ int dvae_emb_bwd(const void* dout, const int64_t* y, float* demb, int B, int HW,
                  int dtype, void* st) {
     if (B <= 0 || HW <= 0 || C <= 0 || num_classes <= 0) DVAE_FAIL(DVAE_EINVAL, "emb_bwd: empty");
     const long total = (long)num_classes * (spatial ? (long)C * HW : C);
+    const int vec = dtype == DVAE_BF16 ? 8 : 4;
+    if (spatial && C % vec == 0 && 256 % (C / vec) == 0 && HW % (256 / (C / vec)) == 0) {
+        const int blocks = num_classes * (HW / (256 / (C / vec)));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((emb_bwd_spatial_kernel<T>), dim3(blocks), dim3(256), 0, S(st), (const T*)dout, y,
+                                             demb, B, HW, C);)
+        DVAE_CHECK_LAUNCH("emb_bwd");
+        return DVAE_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL((emb_bwd_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, S(st),
                                          (const T*)dout, y, demb, B, HW, C, num_classes, spatial);)
     DVAE_CHECK_LAUNCH("emb_bwd");

@@ -114,6 +114,56 @@ __global__ void emb_bwd_kernel(const T* dout, const int64_t* y, float* demb, int
     }
 }
 
+// Spatial embedding (one [C][HW] table row per class): one workgroup per (class, block of pixels).  Wave 0 compacts the
+// samples of the class into an LDS list (ballot + prefix count, 1024 samples per round); every thread then sums its
+// 16-byte channel vector over the list in ascending sample order, four loads in flight (a scan of all B labels with a
+// dependent load per match is a chain of memory round trips).  Reads are whole channel runs of a pixel row; the result
+// goes to the reference's [class][channel][pixel] layout.
+template <typename T>
+__global__ __launch_bounds__(256) void emb_bwd_spatial_kernel(const T* dout, const int64_t* y, float* demb, int B, int HW, int C) {
+    constexpr int VEC = Act<T>::VEC;
+    __shared__ int list[1024];
+    __shared__ int count;
+    const int CV = C / VEC, PXW = 256 / CV;               // channel vectors per pixel; pixels per workgroup
+    const int blocks_per_class = HW / PXW;
+    const int k = blockIdx.x / blocks_per_class, px = (blockIdx.x % blocks_per_class) * PXW + threadIdx.x / CV;
+    const int cv = threadIdx.x % CV;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        if (threadIdx.x < 64) {
+            int n = 0;
+            for (int c0 = b0; c0 < min(B, b0 + 1024); c0 += 64) {
+                const int b = c0 + (int)threadIdx.x;
+                const bool hit = b < B && (int)y[b] == k;
+                const unsigned long long m = __ballot(hit);
+                if (hit) list[n + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = b;
+                n += __popcll(m);
+            }
+            if (threadIdx.x == 0) count = n;
+        }
+        __syncthreads();
+        const int n = count;
+        const T* base = dout + (long)px * C + cv * VEC;
+        for (int i = 0; i < n; i += 4) {
+            float v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Act<T>::load(base + (long)list[min(i + u, n - 1)] * HW * C, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i + u >= n) break;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] += v[u][e];
+            }
+        }
+        __syncthreads();
+    }
+    float* o = demb + (long)k * C * HW + (long)(cv * VEC) * HW + px;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[(long)e * HW] = s[e];
+}
+
 __global__ void philox_normal_kernel(float* out, int B, int per_image, const PhiloxKey key) {
     const int quads = per_image / 4;
     const long total = (long)B * quads;
