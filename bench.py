@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (clean per-kernel timings)")
+    ap.add_argument("--no-batch-reduce", action="store_true", help="reduce every conv's weight-gradient slabs in a launch of its own")
     ap.add_argument("--graph", action="store_true", help="replay the train step from captured HIP graphs (default: launch by launch; "
                     "the step is GPU-bound and the two-stream schedule runs faster outside a graph)")
     ap.add_argument("--no-purify", action="store_true", help="profiling aid: skip the purification region")
@@ -125,6 +126,8 @@ def main():
     init_params(eng)
     if a.no_overlap:
         eng._overlap = False
+    if a.no_batch_reduce:
+        eng._batch_reduce = False
     n_local = max(Bp, (a.images + world - 1) // world)
     g = torch.Generator(device="cuda").manual_seed(rank)
     data = torch.randint(0, 256, (n_local, S, S, 3), generator=g, dtype=torch.uint8, device="cuda")

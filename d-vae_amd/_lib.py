@@ -46,6 +46,10 @@ _SIGS = {
     "dvae_conv_dgrad": (C.c_int, [_P, _P, _P, _I, C.POINTER(ConvDesc), _I, _P]),
     "dvae_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "dvae_conv_wgrad": (C.c_int, [_P, _P, _P, _P, _P, _Z, C.POINTER(ConvDesc), _I, _P]),
+    "dvae_conv_wgrad_partial": (C.c_int, [_P, _P, _I, _P, _Z, C.POINTER(ConvDesc), _I, _P]),
+    "dvae_wgrad_reduce_job_bytes": (_Z, []),
+    "dvae_wgrad_reduce_job": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _I, _P, C.POINTER(C.c_int)]),
+    "dvae_wgrad_reduce_batch": (C.c_int, [_P, _I, _I, _P]),
     "dvae_norm_workspace_bytes": (_Z, [_I, _I, _I]),
     "dvae_norm_fwd_train": (C.c_int, [_P] * 9 + [_P, _Z, _I, _I, _I, _I, _F, _F, _I, _P]),
     "dvae_bn_fwd_eval": (C.c_int, [_P] * 8 + [_I, _I, _I, _F, _I, _P]),

@@ -187,13 +187,9 @@ size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d) {
     return (a > b ? a : b) * sizeof(float);
 }
 
-int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* ws, size_t ws_bytes,
-                    const dvae_conv_desc* d, int dtype, void* st) {
-    WgradPlan W;
-    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
-    int rc = build_wgrad_plan(*d, dtype, W);
-    if (rc) return rc;
-    if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
+// slab (and bias-partial) launches of one weight gradient into ws; fused: the bias partials ride along
+static int wgrad_partials(const WgradPlan& W, const dvae_conv_desc* d, const void* x, const void* dy, void* ws, bool fused,
+                          int dtype, void* st) {
     WgradArgs a;
     a.xg = d->transposed ? dy : x;
     a.d = d->transposed ? x : dy;
@@ -204,10 +200,8 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     a.M = W.M; a.chunk_rows = W.chunk_rows; a.Kpad = W.Kpad; a.CdPad = W.CdPad;
     a.wg_log2 = a.hg_log2 = -1;
     if (!(W.Wg & (W.Wg - 1)) && !(W.Hg & (W.Hg - 1))) { a.wg_log2 = ilog2_exact(W.Wg); a.hg_log2 = ilog2_exact(W.Hg); }
-    float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
-    const bool fused = db && wgrad_bias_fused(W);
     a.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
-    a.bias_taps = W.bias_taps; a.bpart = part;
+    a.bias_taps = W.bias_taps; a.bpart = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
     if (W.halo) {
         static bool lds_set = false;
         if (!lds_set) {
@@ -225,19 +219,43 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     else
         hipLaunchKernelGGL(wgrad_kernel_bf16, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
     DVAE_CHECK_LAUNCH("wgrad");
-    WreduceArgs r;
+    return DVAE_OK;
+}
+
+// the reduction of those slabs into the reference weight (and bias) layout, as a job record
+static void wgrad_reduce_args(const WgradPlan& W, const dvae_conv_desc* d, const void* ws, float* dw, float* db, bool fused,
+                              WreduceArgs& r) {
+    memset(&r, 0, sizeof(r));
     r.ws = (const float*)ws; r.dw = dw; r.S = W.S; r.Kpad = W.Kpad; r.CdPad = W.CdPad; r.Cx = W.Cx;
     r.cx_log2 = W.cx_log2; r.Cd = W.Cd; r.ntaps = W.ntaps; r.sX = W.sX; r.sD = W.sD;
     memcpy(r.woff, W.woff, sizeof(r.woff));
     const long tot = (long)W.Kpad * W.CdPad;
     r.nmain = (int)((tot + 63) / 64);
-    r.bpart = part; r.db = db; r.bias_mode = a.bias_mode; r.bwidth = wgrad_bias_width(W); r.Cb = d->Cout; r.cxs = W.CxS;
+    r.bpart = (const float*)ws + (size_t)W.S * W.Kpad * W.CdPad; r.db = db;
+    r.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
+    r.bwidth = wgrad_bias_width(W); r.Cb = d->Cout; r.cxs = W.CxS;
     r.nbt = 0;
     for (int t = 0; t < W.ntaps && r.nbt < 4; ++t)
         if (W.bias_taps >> t & 1u) r.btap[r.nbt++] = t;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.nmain + (fused ? (d->Cout + 15) / 16 : 0)), dim3(256), 0, S(st), r);
+    r.nblocks = r.nmain + (fused ? (d->Cout + 15) / 16 : 0);
+}
+
+int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                    const dvae_conv_desc* d, int dtype, void* st) {
+    WgradPlan W;
+    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
+    int rc = build_wgrad_plan(*d, dtype, W);
+    if (rc) return rc;
+    if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
+    const bool fused = db && wgrad_bias_fused(W);
+    rc = wgrad_partials(W, d, x, dy, ws, fused, dtype, st);
+    if (rc) return rc;
+    WreduceArgs r;
+    wgrad_reduce_args(W, d, ws, dw, db, fused, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.nblocks), dim3(256), 0, S(st), r);
     DVAE_CHECK_LAUNCH("wgrad_reduce");
     if (db && !fused) {
+        float* part = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
         const void* src = dy;
         const int CS = W.bias_from_gathered ? W.CxS : W.CdS;
         const int rows = W.bias_from_gathered ? W.B * W.Hx * W.Wx : W.M;
@@ -252,6 +270,40 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
                            CS, d->Cout);
         DVAE_CHECK_LAUNCH("colsum_reduce");
     }
+    return DVAE_OK;
+}
+
+int dvae_conv_wgrad_partial(const void* x, const void* dy, int want_bias, void* ws, size_t ws_bytes, const dvae_conv_desc* d,
+                            int dtype, void* st) {
+    WgradPlan W;
+    if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
+    int rc = build_wgrad_plan(*d, dtype, W);
+    if (rc) return rc;
+    if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
+    if (want_bias && !wgrad_bias_fused(W)) DVAE_FAIL(DVAE_EINVAL, "wgrad_partial: this shape's bias gradient needs dvae_conv_wgrad");
+    return wgrad_partials(W, d, x, dy, ws, want_bias != 0, dtype, st);
+}
+
+size_t dvae_wgrad_reduce_job_bytes(void) { return sizeof(WreduceArgs); }
+
+int dvae_wgrad_reduce_job(const void* ws, float* dw, float* db, const dvae_conv_desc* d, int dtype, void* job_host, int* nblocks) {
+    WgradPlan W;
+    if (!d || !job_host || !ws || !dw) DVAE_FAIL(DVAE_EINVAL, "wgrad_reduce_job: null argument");
+    int rc = build_wgrad_plan(*d, dtype, W);
+    if (rc) return rc;
+    if (db && !wgrad_bias_fused(W)) DVAE_FAIL(DVAE_EINVAL, "wgrad_reduce_job: this shape's bias gradient needs dvae_conv_wgrad");
+    WreduceArgs r;
+    wgrad_reduce_args(W, d, ws, dw, db, db != nullptr, r);
+    memcpy(job_host, &r, sizeof(r));
+    if (nblocks) *nblocks = r.nblocks;
+    return DVAE_OK;
+}
+
+int dvae_wgrad_reduce_batch(const void* jobs_dev, int njobs, int max_blocks, void* st) {
+    if (!jobs_dev || njobs <= 0 || max_blocks <= 0) DVAE_FAIL(DVAE_EINVAL, "wgrad_reduce_batch: empty");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)max_blocks, (unsigned)njobs), dim3(256), 0, S(st),
+                       (const WreduceArgs*)jobs_dev);
+    DVAE_CHECK_LAUNCH("wgrad_reduce_batch");
     return DVAE_OK;
 }
 

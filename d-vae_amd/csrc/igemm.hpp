@@ -923,17 +923,18 @@ struct WreduceArgs {
     float* db;
     int bias_mode, bwidth, Cb, cxs, nmain;
     int nbt, btap[4];                // gathered case: the (at most 4) taps whose column sums add up to the bias gradient
+    int nblocks;                     // workgroups of this job: nmain + the bias blocks
 };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_block(const WreduceArgs& a, const int bx) {
     // 64 consecutive slab elements per block; 4 lanes split the S slabs (interleaved), each with
     // independent loads in flight; the 4 partial sums are combined in lane order (deterministic).
     __shared__ float part[4][64];
     const long total = (long)a.Kpad * a.CdPad;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= a.nmain) {                // bias gradient: 16 channels per workgroup, 16 lanes split S
+    if (bx >= a.nmain) {                // bias gradient: 16 channels per workgroup, 16 lanes split S
         const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-        const int c = ((int)blockIdx.x - a.nmain) * 16 + cl;
+        const int c = (bx - a.nmain) * 16 + cl;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         if (c < a.Cb) {
             if (a.bias_mode == 1) {
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
         }
         return;
     }
-    const long e = (long)blockIdx.x * 64 + el;
+    const long e = (long)bx * 64 + el;
     float s0 = 0.f, s1 = 0.f;
     if (e < total) {
         int i = sl;
@@ -975,6 +976,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
     const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
     if (tap >= a.ntaps || c >= a.Cx || cd >= a.Cd) return;
     a.dw[(long)cd * a.sD + (long)c * a.sX + a.woff[tap]] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) { wgrad_reduce_block(a, (int)blockIdx.x); }
+
+// Every conv's slab (and bias) reduction of a backward pass in one launch: blockIdx.y selects a job record in device
+// memory, blockIdx.x that job's block; jobs with fewer blocks than the grid is wide let the surplus exit.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WreduceArgs* jobs) {
+    const WreduceArgs& a = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= a.nblocks) return;
+    wgrad_reduce_block(a, (int)blockIdx.x);
 }
 
 // column sums of an [rows][CS] activation tensor (bias gradients), two deterministic stages

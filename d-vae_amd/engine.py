@@ -255,6 +255,17 @@ class DVAEEngine:
         for c in (64, 32):
             nb = max(nb, self.lib.dvae_norm_workspace_bytes(B, self.S * self.S, c))   # monotone in the group count
         self.wgrad_ws = torch.empty(wbytes // 4 + 16, device=self.dev, dtype=torch.float32)
+        # one workspace slice per conv as well: backward leaves every conv's weight-gradient slabs in its own slice and
+        # reduces all of them in one launch (18 short, latency-bound reductions otherwise)
+        self.wgrad_slice = {}
+        off = 0
+        for name, sp in self.specs.items():
+            n = self.lib.dvae_conv_wgrad_workspace_bytes(C.byref(self._desc(sp, B))) // 4 + 16
+            self.wgrad_slice[name] = (off, n)
+            off += (n + 63) // 64 * 64
+        self.wgrad_ws_all = torch.empty(off, device=self.dev, dtype=torch.float32)
+        self._reduce_jobs = {}        # batch size -> (job table on the device, jobs, widest job)
+        self._batch_reduce = True
         self.norm_ws = torch.empty(nb // 4 + 16, device=self.dev, dtype=torch.float32)
 
     def buf(self, name, shape, dtype=None):
@@ -367,8 +378,36 @@ class DVAEEngine:
         with torch.cuda.stream(side):
             self._wgrad_now(name, x, dy, b)
 
+    def _reduce_table(self, b):
+        """Job records of the one-launch slab reduction for batch size b (built once per b)."""
+        ent = self._reduce_jobs.get(b)
+        if ent is None:
+            nb = self.lib.dvae_wgrad_reduce_job_bytes()
+            names = list(self.specs)
+            host = torch.zeros(len(names) * nb, dtype=torch.uint8)
+            widest = 0
+            for i, name in enumerate(names):
+                off, n = self.wgrad_slice[name]
+                db = self.grad[name + ".bias"] if self.specs[name].bias else None
+                blocks = C.c_int(0)
+                check(self.lib.dvae_wgrad_reduce_job(self.wgrad_ws_all.data_ptr() + 4 * off, ptr(self.grad[name + ".weight"]), ptr(db),
+                                                     C.byref(self.desc(name, b)), self.dtype, host.data_ptr() + i * nb,
+                                                     C.byref(blocks)))
+                widest = max(widest, blocks.value)
+            ent = self._reduce_jobs[b] = (host.to(self.dev), len(names), widest)
+        return ent
+
+    def _wgrad_reduce_all(self, b):
+        jobs, n, widest = self._reduce_table(b)
+        check(self.lib.dvae_wgrad_reduce_batch(ptr(jobs), n, widest, L.stream()))
+
     def _wgrad_now(self, name, x, dy, b):
         sp = self.specs[name]
+        if self._batch_reduce:
+            off, n = self.wgrad_slice[name]
+            check(self.lib.dvae_conv_wgrad_partial(ptr(x), ptr(dy), int(sp.bias), self.wgrad_ws_all.data_ptr() + 4 * off, n * 4,
+                                                   C.byref(self.desc(name, b)), self.dtype, L.stream()))
+            return
         db = self.grad[name + ".bias"] if sp.bias else None
         check(self.lib.dvae_conv_wgrad(ptr(x), ptr(dy), ptr(self.grad[name + ".weight"]), ptr(db), ptr(self.wgrad_ws),
                                        self.wgrad_ws.numel() * 4, C.byref(self.desc(name, b)), self.dtype, L.stream()))
@@ -685,6 +724,14 @@ class DVAEEngine:
         d_c0 = self.act("g.conv1.out", S, 64)
         self._bn_bwd("bn1", d_out, self.act("bn1.out", S, 64), self.act("conv1.out", S, 64), d_c0, None, b * S * S, 64)
         self._wgrad("conv1", L_["x0"], d_c0, b)
+        if self._batch_reduce:                 # every conv of the path has left its slabs: one reduction for all
+            if self._overlap:
+                side = self._side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._wgrad_reduce_all(b)
+            else:
+                self._wgrad_reduce_all(b)
         if self._overlap:
             torch.cuda.current_stream().wait_stream(self._side_stream())
 

@@ -102,6 +102,19 @@ int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int ac
 size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);
 int dvae_conv_wgrad(const void* x, const void* dy, float* dw_ref, float* db_ref /* or NULL */,
                     void* workspace, size_t workspace_bytes, const dvae_conv_desc* d, int dtype, void* stream);
+/* The same gradient in two steps, so that a backward pass reduces the slabs of ALL its convs in one launch (autograd
+ * of the convs in resnet.py:2139-2150, :2008-2050; main_vae_disentangle.py:209).  dvae_conv_wgrad_partial leaves the
+ * per-chunk slabs (and, with want_bias, the bias partials) in a workspace that belongs to this conv until the batch
+ * reduction has run; dvae_wgrad_reduce_job fills one job record (dvae_wgrad_reduce_job_bytes() bytes of host memory)
+ * for that workspace and reports its block count; dvae_wgrad_reduce_batch runs njobs records (copied to device
+ * memory by the caller) with max_blocks = the largest block count among them.  Shapes whose bias gradient cannot ride
+ * on the slab launches return DVAE_EINVAL from the partial / job calls: use dvae_conv_wgrad for those. */
+int dvae_conv_wgrad_partial(const void* x, const void* dy, int want_bias, void* workspace, size_t workspace_bytes,
+                            const dvae_conv_desc* d, int dtype, void* stream);
+size_t dvae_wgrad_reduce_job_bytes(void);
+int dvae_wgrad_reduce_job(const void* workspace, float* dw_ref, float* db_ref /* or NULL */, const dvae_conv_desc* d,
+                          int dtype, void* job_host, int* nblocks /* out, or NULL */);
+int dvae_wgrad_reduce_batch(const void* jobs_dev, int njobs, int max_blocks, void* stream);
 
 /* ---- BatchNorm2d (+ residual add) + ReLU  (resnet.py:27-30) and InstanceNorm2d + ReLU
  * (resnet.py:2014-2015, :2019-2020): one family of kernels over `groups` row groups of
