@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("in_scale_shift", C.c_void_p), ("in_relu", C.c_int32),
-                ("out_stats", C.c_void_p)]
+                ("out_stats", C.c_void_p), ("emb_table", C.c_void_p), ("emb_labels", C.c_void_p), ("emb_out", C.c_void_p)]
 
 
 _P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
@@ -42,6 +42,7 @@ _SIGS = {
     "dvae_conv_pack_batch": (C.c_int, [_P, _I, _I, _P]),
     "dvae_conv_fwd": (C.c_int, [_P, _P, C.POINTER(Epilogue), _P, C.POINTER(ConvDesc), _I, _P]),
     "dvae_conv_supports_input_norm": (C.c_int, [C.POINTER(ConvDesc), _I]),
+    "dvae_conv_supports_emb_out": (C.c_int, [C.POINTER(ConvDesc), _I]),
     "dvae_norm_fwd_stats": (C.c_int, [_P] * 7 + [_Z, _I, _I, _I, _F, _I, _P]),
     "dvae_conv_dgrad": (C.c_int, [_P, _P, _P, _I, C.POINTER(ConvDesc), _I, _P]),
     "dvae_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),

@@ -18,6 +18,11 @@ struct PointArgs {
     const float* scale;        // per output channel or NULL (1)
     const float* shift;        // per output channel or NULL (0)
     int relu, ntiles, Ktot;    // tiles of 128 pixels
+    // optional second output: out2 = out + emb[labels[image]][pixel] (class embedding in activation layout, hw pixels per image)
+    const bf16* emb;
+    const int64_t* labels;
+    bf16* out2;
+    int hw;
 };
 
 constexpr int PT_CIN = 256, PT_N = 128, PT_RS = PT_CIN * 2 + 16, PT_VPP = PT_CIN / 8;   // padded row; 16-byte vectors per row
@@ -86,8 +91,16 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
             }
         }
         bf16* ob = a.out + ((long)tile * 128 + ph * 64) * PT_N + cq * 32;
+        bf16* ob2 = a.out2 ? a.out2 + ((long)tile * 128 + ph * 64) * PT_N + cq * 32 : nullptr;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            bf16x4 o2[4];
+            const bf16* erow = nullptr;
+            if (a.out2) {                                 // this lane's pixel: its image's class row of the table
+                const int m = tile * 128 + ph * 64 + p * 32 + r;
+                const int b = m / a.hw, pxi = m - b * a.hw;
+                erow = a.emb + ((long)a.labels[b] * a.hw + pxi) * PT_N + cq * 32;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = 8 * g + 4 * h;
@@ -101,6 +114,11 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
                     o[k] = (bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(stg + r * PT_SRS + nl * 2) = o;
+                if (a.out2) {
+                    const bf16x4 e = *reinterpret_cast<const bf16x4*>(erow + nl);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o2[g][k] = (bf16)((float)o[k] + (float)e[k]);   // the stored value + the embedding
+                }
             }
             wave_lds_fence();
 #pragma unroll
@@ -110,6 +128,18 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
                 *reinterpret_cast<u32x4*>(ob + (long)(p * 32 + px) * PT_N + sc8 * 8) = v;
             }
             wave_lds_fence();
+            if (a.out2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<bf16x4*>(stg + r * PT_SRS + (8 * g + 4 * h) * 2) = o2[g];
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int px = i * 16 + sp;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * PT_SRS + sc8 * 16);
+                    *reinterpret_cast<u32x4*>(ob2 + (long)(p * 32 + px) * PT_N + sc8 * 8) = v;
+                }
+                wave_lds_fence();
+            }
         }
     }
 }
@@ -125,9 +155,11 @@ static bool point_applicable(const GemmPlan& P) {
 
 static bool try_launch_point_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                   const float* shift, const void* res, int relu, int accumulate, int out_f32,
-                                  hipStream_t st) {
+                                  hipStream_t st, const void* emb = nullptr, const int64_t* labels = nullptr,
+                                  void* out2 = nullptr) {
     if (res || accumulate || out_f32 || !point_applicable(P)) return false;
     PointArgs a;
+    a.emb = (const bf16*)emb; a.labels = labels; a.out2 = (bf16*)out2; a.hw = P.Hout * P.Wout;
     a.in = (const bf16*)in; a.wp = (const bf16*)wp + P.ph[0].koff; a.out = (bf16*)out; a.scale = scale; a.shift = shift;
     a.relu = relu; a.ntiles = (int)((long)P.B * P.Hout * P.Wout / 128); a.Ktot = P.Ktot;
     static bool attr_set = false;

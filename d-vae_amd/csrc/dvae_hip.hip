@@ -146,11 +146,19 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
         DVAE_CHECK_LAUNCH("conv_stem");
         return DVAE_OK;
     }
-    if (try_launch_point_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+    if (try_launch_point_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), e.emb_table, e.emb_labels,
+                              e.emb_out)) {
         DVAE_CHECK_LAUNCH("conv_point");
         return DVAE_OK;
     }
+    if (e.emb_out) DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused embedding output unavailable for this launch (see dvae_conv_supports_emb_out)");
     return launch_igemm<bf16>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st));
+}
+
+int dvae_conv_supports_emb_out(const dvae_conv_desc* d, int dtype) {
+    GemmPlan P;
+    if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P)) return 0;
+    return point_applicable(P) ? 1 : 0;
 }
 
 int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype) {

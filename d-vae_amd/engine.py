@@ -231,6 +231,9 @@ class DVAEEngine:
         self._fuse_stats = all(self.lib.dvae_conv_out_stats_floats(C.byref(self._desc(self.specs[n], 1)), dtype) > 0
                                for n in ("decoder1.1", "decoder2.0"))
         self._fuse_head = bool(self.lib.dvae_fc_reparam_supported(C.byref(self._desc(self.specs["fc"], 1)), self.Ld, dtype))
+        # post_conv can leave decoder_p's input (z + class embedding) behind as a second output
+        self._fuse_emb = bool(cfg.sample_wise and not cfg.use_y and cfg.spatial_emb and
+                              self.lib.dvae_conv_supports_emb_out(C.byref(self._desc(self.specs["post_conv"], 1)), dtype))
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
         self._overlap = self.dev.type == "cuda"   # weight gradients on a side stream (see _wgrad)
 
@@ -346,8 +349,11 @@ class DVAEEngine:
     # primitive launches
     # ------------------------------------------------------------------------------------------
     def _conv(self, name, x, y, b, scale=None, shift=None, residual=None, relu=False, out_f32=False, in_ss=None, in_relu=False,
-              out_stats=None):
-        ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu), ptr(out_stats))
+              out_stats=None, emb=None):
+        """emb = (packed table, labels, second output): the conv also writes y + table[label] (decoder_p's input)."""
+        et, el, eo = emb if emb is not None else (None, None, None)
+        ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu), ptr(out_stats),
+                      ptr(et), ptr(el), ptr(eo))
         pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
         if pr:
             pr[1][0].record()
@@ -488,7 +494,7 @@ class DVAEEngine:
         ``need_rec=False`` (inference only) leaves the reconstruction branch out and returns (None, p): for callers
         that read nothing but the perturbation of this pass (main_vae_disentangle.py:61-62)."""
         stem_out = self.stem(x0, b, train)
-        _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train)
+        _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train, y=y)
         if isinstance(eps, PhiloxEps):
             eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
         rec_pre = self._decoder("decoder", z, b, train) if (train or need_rec) else None
@@ -548,9 +554,15 @@ class DVAEEngine:
             a = out
         return a
 
-    def latent(self, stem_out, eps, b, keep_eps=True, need_mulv=True):
+    def latent(self, stem_out, eps, b, keep_eps=True, need_mulv=True, y=None):
         """encode (fc_mu|fc_var as one GEMM) -> reparameterise (+ KL partial sums) -> post_conv.
-        resnet.py:2197-2199, :2245-2246, :2257-2259."""
+        resnet.py:2197-2199, :2245-2246, :2257-2259.  With labels y (and where the conv supports it) post_conv also
+        writes decoder_p's input z + emb_p(y) (resnet.py:2212, :2219); perturb() then skips its own pass."""
+        emb = None
+        self._emb_done = False
+        if y is not None and self._fuse_emb:
+            emb = (self.emb_table, y, self.act("dec_p.in", self.h, 128))
+            self._emb_done = True
         if not self.packed_valid:
             self.pack_weights()
         h = self.h
@@ -564,7 +576,7 @@ class DVAEEngine:
                                                       ptr(z1), C.byref(self.desc("fc", b)), self.Ld, ptr(eps.index), eps.first,
                                                       self.seed, eps.stream_id, self.dtype, L.stream()))
             z = self.act("z", h, 128)
-            self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"])
+            self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"], emb=emb)
             return None, z1, z
         mulv = self.act("mulv.act", h, 2 * self.Ld) if lean else self.act("mulv", h, 2 * self.Ld, f32=True)
         self._conv("fc", stem_out, mulv, b, shift=self.param["fc.bias"], out_f32=not lean)
@@ -577,13 +589,16 @@ class DVAEEngine:
             check(self.lib.dvae_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z1), ptr(self.kl_partial), b * h * h, self.Ld,
                                                self.dtype, L.stream()))
         z = self.act("z", h, 128)
-        self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"])
+        self._conv("post_conv", z1, z, b, shift=self.param["post_conv.bias"], emb=emb)
         return mulv, z1, z
 
     def perturb(self, stem_out, z, y, b, train=True):
         """decoder_p(Embedding + stem_out | Embedding + z | Embedding), resnet.py:2211-2221."""
         cfg, h = self.cfg, self.h
         ep = self.act("dec_p.in", h, 128)
+        if getattr(self, "_emb_done", False):            # post_conv has written it already
+            self._emb_done = False
+            return self._decoder("decoder_p", ep, b, train)
         add = None
         if cfg.sample_wise:
             add = stem_out if cfg.use_y else z

@@ -70,6 +70,13 @@ typedef struct dvae_epilogue {
      * [B][H*W/32][2][act channels]; dvae_norm_stats_from_chunks turns them into mean / invstd / scale-shift.
      * dvae_conv_out_stats_floats() gives the size, 0 where the conv cannot produce them; NULL = off. */
     float* out_stats;
+    /* Optional second output (inference): emb_out = y + emb_table[emb_labels[b]], the input of decoder_p
+     * (emb_p(y).reshape(stem_out.shape) + z, resnet.py:2212, :2219), with emb_table the spatial table in activation
+     * layout as dvae_emb_pack leaves it ([classes][H*W][act channels]) and emb_out shaped like y.  Same values as
+     * dvae_emb_add_fwd on the stored y.  Only where dvae_conv_supports_emb_out() says so; emb_out == NULL = off. */
+    const void* emb_table;
+    const int64_t* emb_labels;
+    void* emb_out;
 } dvae_epilogue;
 
 const char* dvae_version(void);
@@ -97,6 +104,7 @@ int dvae_conv_pack_batch(const void* jobs_dev, int njobs, int dtype, void* strea
 int dvae_conv_fwd(const void* x, const void* w_packed_fwd, const dvae_epilogue* ep, void* y,
                   const dvae_conv_desc* d, int dtype, void* stream);
 int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype);
+int dvae_conv_supports_emb_out(const dvae_conv_desc* d, int dtype);
 int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int accumulate,
                     const dvae_conv_desc* d, int dtype, void* stream);
 size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);

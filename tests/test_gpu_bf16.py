@@ -371,3 +371,36 @@ def test_model_forward_bf16_64x64(train):
         eng.adam_step()
         torch.cuda.synchronize()
         assert np.isfinite(float(eng.scal[L.SCAL["grad_norm"]]))
+
+
+def test_post_conv_second_output_equals_embedding_add():
+    """post_conv with the fused second output (z + class embedding, decoder_p's input) against the conv followed by the
+    stand-alone embedding add: same bits for both outputs."""
+    lib = L.lib()
+    B, hw, ncls = 6, 16, 10
+    g = torch.Generator().manual_seed(9)
+    d = L.ConvDesc(B, hw, hw, 256, 128, 1, 1, 1, 0, 0)
+    assert lib.dvae_conv_supports_emb_out(C.byref(d), L.BF16) == 1
+    st = L.stream()
+    w = torch.randn(128, 256, 1, 1, generator=g) / 16
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), 0), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().data_ptr(), pk.data_ptr(), C.byref(d), 0, L.BF16, st))
+    x = torch.randn(B, hw, hw, 256, generator=g).cuda().bfloat16()
+    bias = torch.randn(128, generator=g).cuda()
+    emb = torch.randn(ncls, 128 * hw * hw, generator=g).cuda()
+    table = torch.zeros(ncls * hw * hw * 128, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_emb_pack(emb.data_ptr(), table.data_ptr(), ncls, hw * hw, 128, 1, L.BF16, st))
+    y = torch.randint(0, ncls, (B,), generator=g).cuda()
+    z_ref = torch.empty(B, hw, hw, 128, device="cuda", dtype=torch.bfloat16)
+    ep = L.Epilogue(None, bias.data_ptr(), None, 0, 0)
+    L.check(lib.dvae_conv_fwd(x.data_ptr(), pk.data_ptr(), C.byref(ep), z_ref.data_ptr(), C.byref(d), L.BF16, st))
+    e_ref = torch.empty_like(z_ref)
+    L.check(lib.dvae_emb_add_fwd(table.data_ptr(), y.data_ptr(), z_ref.data_ptr(), e_ref.data_ptr(), B, hw * hw, 128, 1, L.BF16, st))
+    z, e = torch.empty_like(z_ref), torch.empty_like(z_ref)
+    ep2 = L.Epilogue(None, bias.data_ptr(), None, 0, 0, None, 0, None, table.data_ptr(), y.data_ptr(), e.data_ptr())
+    L.check(lib.dvae_conv_fwd(x.data_ptr(), pk.data_ptr(), C.byref(ep2), z.data_ptr(), C.byref(d), L.BF16, st))
+    torch.cuda.synchronize()
+    assert torch.equal(z, z_ref) and torch.equal(e, e_ref)
+    # a conv that cannot do it must say so rather than drop the request
+    d2 = L.ConvDesc(B, hw, hw, 128, 128, 3, 3, 1, 1, 0)
+    assert lib.dvae_conv_supports_emb_out(C.byref(d2), L.BF16) == 0
