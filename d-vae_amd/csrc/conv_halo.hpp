@@ -223,6 +223,24 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     bf16* outb = reinterpret_cast<bf16*>(a.out);
     const bf16* addb = reinterpret_cast<const bf16*>(a.add);
 
+    // residual + ReLU of a bf16 output are applied where the layouts agree: on the coalesced side, while the tile is
+    // drained (the residual rows arrive as whole pixel rows too), instead of a round trip through the patch per tile
+    // (plain instantiation only: the feature variants have no registers to carry the residual rows across tiles)
+    const bool res_drain = !IN_SS && !STATS && staged && a.add != nullptr && !a.add_after_relu;
+    u32x4 radd[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) radd[i] = u32x4{0u, 0u, 0u, 0u};
+    auto finish_piece = [&](const u32x4& piece, const u32x4& res) -> u32x4 {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(&piece), rr = *reinterpret_cast<const bf16x8*>(&res);
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float f = (float)x[c] + (float)rr[c];
+            if (a.relu) f = fmaxf(f, 0.f);
+            o[c] = (bf16)f;
+        }
+        return *reinterpret_cast<u32x4*>(&o);
+    };
     int tile = blockIdx.x;
     if (tile < ntiles) {
 #pragma unroll
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         HALO_STAMP(2);
         const int next = tile + gridDim.x, prev = tile - gridDim.x;
         const bool drain = staged && it > 0, fetch_add = staged && a.add != nullptr, fetch_next = next < ntiles;
-        u32x4 radd[NI], dreg;
+        u32x4 dreg;
         // q-th global access of this tile (compile-time q): drain reads/stores, add fetches, halo fetches
         auto mem_op = [&](int q) {
             if (q <= NI) {
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
                         for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
                     }
                     if (q > 0) {
+                        if (res_drain) dreg = finish_piece(dreg, radd[q - 1]);   // radd still holds the previous tile's rows
                         if (chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(prev, q - 1)) = dreg;
                         if (STATS && a.stats) stats_add(dreg);
                     }
@@ -350,8 +369,8 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
                     }
                 wave_lds_fence();
             };
-            if (a.add && !a.add_after_relu) add_staged();
-            if (a.relu) {
+            if (a.add && !a.add_after_relu && !res_drain) add_staged();
+            if (a.relu && !res_drain) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -380,7 +399,8 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const u32x4 piece = *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
+            u32x4 piece = *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
+            if (res_drain) piece = finish_piece(piece, radd[i]);
             if (chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(last, i)) = piece;
             if (STATS && a.stats) stats_add(piece);
         }
