@@ -203,9 +203,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 32, 64);
         if (sp == 0 && chunk_live) {
-            const int tpi = 1 << (a.lx + a.ly);
-            float* dst = a.stats + (((long)(tile >> (a.lx + a.ly)) * (tpi * 8) + (tile & (tpi - 1)) * 8 + wave) * 2) * a.NS +
-                         n0 + sc8 * 8;
+            float* dst = a.stats + (((long)(tile >> (a.lx + a.ly)) * 8 + wave) * 2) * a.NS + n0 + sc8 * 8;
             f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
             f32x4 q0 = {v[8], v[9], v[10], v[11]}, q1 = {v[12], v[13], v[14], v[15]};
             *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
@@ -241,26 +239,42 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         }
         return *reinterpret_cast<u32x4*>(&o);
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
+    // Tile order.  Plain launches stride the tiles over the grid.  The feature variants walk whole images (a
+    // workgroup's image j is blockIdx.x + j * gridDim.x, tiles in order).  With statistics the sums then run over all
+    // tiles of an image, the cross-lane reduction and the store happen once per image -- per tile they cost 10 % of the
+    // kernel -- and an image's chunks do not depend on the batch it is in.  The normalising consumer follows the same
+    // order so that an image stays on the XCD (blockIdx.x mod 8) whose L2 its producer wrote it through.
+    constexpr bool IMO = IN_SS || STATS;
+    const int ltpi = a.lx + a.ly, tpi_m = (1 << ltpi) - 1;
+    auto tile_at = [&](int i) -> int {
+        if (!IMO) return blockIdx.x + i * (int)gridDim.x;
+        return ((blockIdx.x + (i >> ltpi) * (int)gridDim.x) << ltpi) + (i & tpi_m);
+    };
+    const int nit = IMO ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) << ltpi
+                        : (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = tile_at(0);
+    if (nit > 0) {
 #pragma unroll
         for (int k = 0; k < HV; ++k) load_halo_vec(tile, k);
     }
     int it = 0;
-    for (; tile < ntiles; tile += gridDim.x, ++it) {
+#pragma nounroll                                           // also keeps the first iteration from being peeled off
+    for (; it < nit; ++it, tile = tile_at(it)) {
         HALO_STAMP(0);
         store_halo();
         HALO_STAMP(1);
         __syncthreads();                                   // halo (and, first time, weights) visible
         HALO_STAMP(2);
-        const int next = tile + gridDim.x, prev = tile - gridDim.x;
-        const bool drain = staged && it > 0, fetch_add = staged && a.add != nullptr, fetch_next = next < ntiles;
+        const int next = tile_at(it + 1), prev = tile_at(it - 1);
+        const bool drain = staged && it > 0, fetch_add = staged && a.add != nullptr, fetch_next = it + 1 < nit;
+        // statistics: the drained tile (it - 1) opens / closes an image
+        const bool st_open = ((it - 1) & tpi_m) == 0, st_close = ((it - 1) & tpi_m) == tpi_m;
         u32x4 dreg;
         // q-th global access of this tile (compile-time q): drain reads/stores, add fetches, halo fetches
         auto mem_op = [&](int q) {
             if (q <= NI) {
                 if (drain) {
-                    if (q == 0 && STATS && a.stats) {
+                    if (q == 0 && STATS && a.stats && st_open) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
                     }
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
                         if (STATS && a.stats) stats_add(dreg);
                     }
                     if (q < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (q * PPI + sp) * SRS + sc8 * 16);
-                    if (q == NI && STATS && a.stats) stats_flush(prev);
+                    if (q == NI && STATS && a.stats && st_close) stats_flush(prev);
                 }
             } else if (q <= 2 * NI) {
                 const int i = q - NI - 1;
@@ -394,9 +408,11 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     }
     // ---- the last tile's output is still parked in the patch ----
     if (staged && it > 0) {
-        const int last = tile - gridDim.x;
+        const int last = tile_at(it - 1);
+        if (((it - 1) & tpi_m) == 0) {                     // one tile per image: the last tile opens its image too
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+            for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             u32x4 piece = *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
@@ -467,7 +483,9 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     // persistent workgroups, tiles strided over the grid: one per CU where the LDS footprint allows no more, two for the
     // small shapes (32 -> 32 channels: 66 KB), whose tiles are mostly serial latency that a second workgroup hides
     const int per_cu = 2 * halo_lds_bytes_of(P.CgS, NT, TW) <= HALO_LDS_MAX ? 2 : 1;
-    dim3 grid(ntiles < 256 * per_cu ? ntiles : 256 * per_cu, P.Npad / NT), block(512);
+    int gx = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    if ((stats || in_ss) && gx > P.B) gx = P.B;           // the feature variants walk whole images
+    dim3 grid(gx, P.Npad / NT), block(512);
     const bool f_in = in_ss != nullptr, f_st = stats != nullptr;
 #define HALO_CASE(C, N, T, FI, FS)                                                                           \
     if (P.CgS == C && NT == N && TW == T && f_in == FI && f_st == FS) {                                      \

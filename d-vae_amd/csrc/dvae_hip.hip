@@ -388,7 +388,7 @@ int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, fl
 size_t dvae_conv_out_stats_floats(const dvae_conv_desc* d, int dtype) {
     GemmPlan P;
     if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P) || !halo_features_applicable(P)) return 0;
-    return (size_t)P.B * (P.Hout * P.Wout / 32) * 2 * P.NS;
+    return (size_t)P.B * 8 * 2 * P.NS;                    // per image: 8 chunks (one per wave of the tile walk) of H*W/8 pixels
 }
 
 int dvae_norm_stats_from_chunks(const float* chunks, int chunk_rows, const float* gamma, const float* beta, float* save_mean,

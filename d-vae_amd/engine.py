@@ -620,8 +620,8 @@ class DVAEEngine:
         fuse = (not train) and self._fuse_in
         if fuse and self._fuse_stats:
             # statistics ride on the producing conv's store, normalisation on the consuming conv's load
-            ch1 = self.buf(d + ".in1.chunks", (self.B, S * S // 32, 2, d2.shape[-1]), torch.float32)
-            ch2 = self.buf(d + ".in2.chunks", (self.B, S * S // 32, 2, d4.shape[-1]), torch.float32)
+            ch1 = self.buf(d + ".in1.chunks", (self.B, 8, 2, d2.shape[-1]), torch.float32)
+            ch2 = self.buf(d + ".in2.chunks", (self.B, 8, 2, d4.shape[-1]), torch.float32)
             self._conv(d + "1.1", d1, d2, b, shift=self.param[d + "1.1.bias"], out_stats=ch1)
             ss1 = self._in_stats_chunks(d + ".in1", ch1, b, 64)
             self._conv(d + "2.0", d2, d4, b, shift=self.param[d + "2.0.bias"], in_ss=ss1, in_relu=True, out_stats=ch2)
@@ -656,7 +656,7 @@ class DVAEEngine:
         mean = self.buf(tag + ".mean", (self.B, c), torch.float32)
         invstd = self.buf(tag + ".invstd", (self.B, c), torch.float32)
         ss = self.buf(tag + ".ss", (self.B, 2, c), torch.float32)
-        check(self.lib.dvae_norm_stats_from_chunks(ptr(chunks), 32, None, None, ptr(mean), ptr(invstd), ptr(ss), b,
+        check(self.lib.dvae_norm_stats_from_chunks(ptr(chunks), self.S * self.S // 8, None, None, ptr(mean), ptr(invstd), ptr(ss), b,
                                                    self.S * self.S, c, IN_EPS, self.dtype, L.stream()))
         return ss
 

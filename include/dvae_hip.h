@@ -66,8 +66,9 @@ typedef struct dvae_epilogue {
     const float* in_scale_shift;
     int32_t in_relu;
     /* Optional fused statistics of the stored output (the InstanceNorm2d that follows the conv, resnet.py:2030-2046):
-     * per image, per 32-pixel chunk and per channel the sum and the sum of squares, fp32
-     * [B][H*W/32][2][act channels]; dvae_norm_stats_from_chunks turns them into mean / invstd / scale-shift.
+     * per image, per chunk of H*W/8 pixels and per channel the sum and the sum of squares, fp32
+     * [B][8][2][act channels]; dvae_norm_stats_from_chunks (chunk_rows = H*W/8) turns them into mean / invstd /
+     * scale-shift.  An image's chunks do not depend on the batch it is in.
      * dvae_conv_out_stats_floats() gives the size, 0 where the conv cannot produce them; NULL = off. */
     float* out_stats;
     /* Optional second output (inference): emb_out = y + emb_table[emb_labels[b]], the input of decoder_p

@@ -259,7 +259,7 @@ def test_conv_output_statistics_bf16(cin, cout, hin, tr):
     st = L.stream()
     n = lib.dvae_conv_out_stats_floats(C.byref(d), L.BF16)
     cs = L.act_channels(cout, L.BF16)
-    assert n == B * (hin * hin // 32) * 2 * cs
+    assert n == B * 8 * 2 * cs
     assert lib.dvae_conv_out_stats_floats(C.byref(d), L.F32) == 0
     pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
     L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
@@ -272,8 +272,8 @@ def test_conv_output_statistics_bf16(cin, cout, hin, tr):
     for tag in ("fused", "alone"):
         out[tag] = [torch.empty(B, cs, device="cuda"), torch.empty(B, cs, device="cuda"), torch.empty(B, 2, cs, device="cuda")]
     m, i, s = out["fused"]
-    L.check(lib.dvae_norm_stats_from_chunks(chunks.data_ptr(), 32, None, None, m.data_ptr(), i.data_ptr(), s.data_ptr(), B,
-                                            hin * hin, cs, 1e-5, L.BF16, st))
+    L.check(lib.dvae_norm_stats_from_chunks(chunks.data_ptr(), hin * hin // 8, None, None, m.data_ptr(), i.data_ptr(),
+                                            s.data_ptr(), B, hin * hin, cs, 1e-5, L.BF16, st))
     m, i, s = out["alone"]
     ws = torch.empty(lib.dvae_norm_workspace_bytes(B, hin * hin, cs) // 4 + 4, device="cuda")
     L.check(lib.dvae_norm_fwd_stats(ya.data_ptr(), None, None, m.data_ptr(), i.data_ptr(), s.data_ptr(), ws.data_ptr(),
