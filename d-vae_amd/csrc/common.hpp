@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/dvae_hip.h"
 
 namespace dvae {
@@ -97,5 +99,19 @@ __device__ inline float block_sum_256(float v, float* red) {
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
+
+// Opt-in of a kernel to more than 64 KB of dynamic LDS.  The attribute belongs to the (kernel, device) pair and a
+// process may drive several devices, so each launch site keeps one bit per device ordinal.
+struct LdsOptIn {
+    std::atomic<unsigned long long> done{0ull};
+    void ensure(const void* fn, int bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);   // a failure shows up at the launch check
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 }  // namespace dvae

@@ -491,12 +491,8 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     if (P.CgS == C && NT == N && TW == T && f_in == FI && f_st == FS) {                                      \
         constexpr int lds = halo_lds_bytes<C, N, T>();                                                       \
         if (lds > HALO_LDS_MAX) return false;                                                                \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16_kernel<C, N, T, FI, FS>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
+        static LdsOptIn lds_opt;                                                                             \
+        lds_opt.ensure(reinterpret_cast<const void*>(&conv_halo_bf16_kernel<C, N, T, FI, FS>), lds);         \
         hipLaunchKernelGGL((conv_halo_bf16_kernel<C, N, T, FI, FS>), grid, block, lds, st, a);               \
         return true;                                                                                         \
     }

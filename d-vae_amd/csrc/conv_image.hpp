@@ -395,12 +395,8 @@ static bool try_launch_image_full(const GemmPlan& P, const void* in, const void*
     }
     constexpr int lds = image_full_lds_bytes<128, 64>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static LdsOptIn lds_opt;
+    lds_opt.ensure(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>), lds);
     dim3 grid(P.B < 256 ? P.B : 256), block(512);
     hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>), grid, block, lds, st, a);
     return true;
@@ -433,12 +429,8 @@ static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void*
     dim3 grid(P.B < 256 ? P.B : 256), block(512);
 #define IMAGE_CASE(NS_, MASK_)                                                                                      \
     if (g.nslab == NS_ && g.lastmask == MASK_) {                                                                    \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, NS_, MASK_>),  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                             \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
+        static LdsOptIn lds_opt;                                                                                    \
+        lds_opt.ensure(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, NS_, MASK_>), lds);           \
         hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, NS_, MASK_>), grid, block, lds, st, a);                 \
         return true;                                                                                                \
     }
@@ -470,12 +462,8 @@ static bool try_launch_image_zf(const GemmPlan& P, const void* in, const void* w
     if (a.nslab == NS_) {                                                                                               \
         constexpr int lds = image_zf_lds_bytes<128, 64, NS_>();                                                         \
         static_assert(lds <= 160 * 1024, "LDS budget");                                                                 \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, NS_, (1u << NS_) - 1u, true>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                 \
-            attr_set = true;                                                                                            \
-        }                                                                                                               \
+        static LdsOptIn lds_opt;                                                                                        \
+        lds_opt.ensure(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, NS_, (1u << NS_) - 1u, true>), lds); \
         hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, NS_, (1u << NS_) - 1u, true>), grid, block, lds, st, a);    \
         return true;                                                                                                    \
     }

@@ -162,12 +162,8 @@ static bool try_launch_point_bf16(const GemmPlan& P, const void* in, const void*
     a.emb = (const bf16*)emb; a.labels = labels; a.out2 = (bf16*)out2; a.hw = P.Hout * P.Wout;
     a.in = (const bf16*)in; a.wp = (const bf16*)wp + P.ph[0].koff; a.out = (bf16*)out; a.scale = scale; a.shift = shift;
     a.relu = relu; a.ntiles = (int)((long)P.B * P.Hout * P.Wout / 128); a.Ktot = P.Ktot;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_point_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PT_LDS);
-        attr_set = true;
-    }
+    static LdsOptIn lds_opt;
+    lds_opt.ensure(reinterpret_cast<const void*>(&conv_point_bf16_kernel), PT_LDS);
     const int grid = a.ntiles < 256 ? a.ntiles : 256;
     hipLaunchKernelGGL(conv_point_bf16_kernel, dim3(grid), dim3(512), PT_LDS, st, a);
     return true;

@@ -211,12 +211,8 @@ static int wgrad_partials(const WgradPlan& W, const dvae_conv_desc* d, const voi
     a.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
     a.bias_taps = W.bias_taps; a.bpart = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
     if (W.halo) {
-        static bool lds_set = false;
-        if (!lds_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo_bf16_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
-            lds_set = true;
-        }
+        static LdsOptIn lds_opt;
+        lds_opt.ensure(reinterpret_cast<const void*>(&wgrad_halo_bf16_kernel), WH_LDS);
         WgradHaloArgs h;
         h.xg = (const bf16*)a.xg; h.d = (const bf16*)a.d; h.ws = a.ws;
         h.H = W.Hg; h.W = W.Wg; h.tiles_x = W.Wg / 32; h.tiles_y = W.Hg / 4; h.ntiles = W.halo_tiles; h.per = W.halo_per;
