@@ -244,12 +244,13 @@ def test_fused_encoder_head_bf16(B, Ld):
     assert rel_err(from_act(z, Ld), z_ref) < 6e-3
 
 
-@pytest.mark.parametrize("cin,cout,hin,tr", [(64, 64, 32, True), (64, 32, 32, True), (32, 64, 64, False)])
-def test_conv_output_statistics_bf16(cin, cout, hin, tr):
+@pytest.mark.parametrize("cin,cout,hin,tr,B", [(64, 64, 32, True, 5), (64, 32, 32, True, 5), (32, 64, 64, False, 5),
+                                               (64, 32, 32, True, 600)])
+def test_conv_output_statistics_bf16(cin, cout, hin, tr, B):
     """InstanceNorm2d statistics (resnet.py:2030-2046) gathered by the producing conv's store against the
-    stand-alone statistics kernel on the stored tensor: same values up to fp32 summation order."""
+    stand-alone statistics kernel on the stored tensor: same values up to fp32 summation order.  With 600 images a
+    workgroup walks two or three of them (the sums are reset and flushed inside its tile loop)."""
     lib = L.lib()
-    B = 5
     g = torch.Generator().manual_seed(3 + cout + hin)
     sp = ConvSpec("t", cin, cout, 3, 1, 1, tr, hin, True)
     w = torch.randn(sp.wshape, generator=g) / (cin * 9) ** 0.5
@@ -284,6 +285,46 @@ def test_conv_output_statistics_bf16(cin, cout, hin, tr):
     # and against torch on the stored values
     y = from_act(ya, cout).float()
     assert rel_err(out["fused"][0][:, :cout].cpu(), y.mean(dim=(2, 3))) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,B,f32out", [(64, 32, 3, False), (64, 32, 600, False), (32, 3, 700, True)])
+def test_conv_input_normalisation_prologue_bf16(cin, cout, B, f32out):
+    """The decoders' convs consume ReLU(InstanceNorm2d(x)) (resnet.py:2030-2046): the per-image scale / shift and the
+    ReLU applied while the conv stages its input, against the same conv on a tensor normalised beforehand.  600 / 700
+    images: more than the launch has workgroups, so a workgroup changes image (and scale / shift) inside its loop."""
+    lib = L.lib()
+    hin = 32
+    g = torch.Generator().manual_seed(11 + cout + B)
+    sp = ConvSpec("t", cin, cout, 3, 1, 1, True, hin, True)
+    w = torch.randn(sp.wshape, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g).cuda()
+    d = L.ConvDesc(B, hin, hin, cin, cout, 3, 3, 1, 1, 1)
+    assert lib.dvae_conv_supports_input_norm(C.byref(d), L.BF16) == 1
+    st = L.stream()
+    cs_in, cs_out = L.act_channels(cin, L.BF16), L.act_channels(cout, L.F32 if f32out else L.BF16)
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    xa = (torch.randn(B, hin, hin, cs_in, generator=g) * 1.5).cuda().bfloat16()
+    ss = torch.empty(B, 2, cs_in)
+    ss[:, 0] = torch.rand(B, cs_in, generator=g) + 0.5
+    ss[:, 1] = torch.randn(B, cs_in, generator=g) * 0.5
+    ss = ss.cuda()
+    odt = torch.float32 if f32out else torch.bfloat16
+    y_fused = torch.empty(B, hin, hin, cs_out, device="cuda", dtype=odt)
+    y_plain = torch.empty_like(y_fused)
+    ep = L.Epilogue(None, L.ptr(bias), None, 0, int(f32out), ss.data_ptr(), 1)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), y_fused.data_ptr(), C.byref(d), L.BF16, st))
+    xn = torch.relu(xa.float() * ss[:, 0, None, None, :] + ss[:, 1, None, None, :]).bfloat16()
+    ep = L.Epilogue(None, L.ptr(bias), None, 0, int(f32out))
+    L.check(lib.dvae_conv_fwd(xn.data_ptr(), pk.data_ptr(), C.byref(ep), y_plain.data_ptr(), C.byref(d), L.BF16, st))
+    torch.cuda.synchronize()
+    # the prologue may fuse the multiply-add (one rounding less before the bf16 rounding of the staged value): a few
+    # staged values differ by one bf16 step, and a bf16 output may then round the other way (one step = 4e-3 of a value)
+    assert rel_err(y_fused[..., :cout].float().cpu(), y_plain[..., :cout].float().cpu()) < (1e-3 if f32out else 6e-3)
+    # per image: an image normalised with another image's scale / shift would be off by O(1)
+    per_img = (y_fused[..., :cout].float() - y_plain[..., :cout].float()).abs().amax(dim=(1, 2, 3))
+    scale = y_plain[..., :cout].float().abs().amax()
+    assert (per_img < 0.05 * scale).all()
 
 
 @pytest.mark.parametrize("dtype", [1, 0], ids=["bf16", "f32"])
