@@ -91,15 +91,23 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
             }
         }
         bf16* ob = a.out + ((long)tile * 128 + ph * 64) * PT_N + cq * 32;
-        bf16* ob2 = a.out2 ? a.out2 + ((long)tile * 128 + ph * 64) * PT_N + cq * 32 : nullptr;
+        // second output: a tile lies inside one image (128 divides hw), so its class row of the table is uniform; the
+        // embedding is added on the coalesced side, to the 16-byte pieces on their way to `out`
+        bf16* ob2 = nullptr;
+        const bf16* eb = nullptr;
+        if (a.out2) {
+            const long m0 = (long)tile * 128;
+            const int b = (int)(m0 / a.hw), px0 = (int)(m0 - (long)b * a.hw) + ph * 64;
+            ob2 = a.out2 + (m0 + ph * 64) * PT_N + cq * 32;
+            eb = a.emb + ((long)a.labels[b] * a.hw + px0) * PT_N + cq * 32;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            bf16x4 o2[4];
-            const bf16* erow = nullptr;
-            if (a.out2) {                                 // this lane's pixel: its image's class row of the table
-                const int m = tile * 128 + ph * 64 + p * 32 + r;
-                const int b = m / a.hw, pxi = m - b * a.hw;
-                erow = a.emb + ((long)a.labels[b] * a.hw + pxi) * PT_N + cq * 32;
+            u32x4 ev[2];
+            if (a.out2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    ev[i] = *reinterpret_cast<const u32x4*>(eb + (long)(p * 32 + i * 16 + sp) * PT_N + sc8 * 8);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -114,11 +122,6 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
                     o[k] = (bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(stg + r * PT_SRS + nl * 2) = o;
-                if (a.out2) {
-                    const bf16x4 e = *reinterpret_cast<const bf16x4*>(erow + nl);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o2[g][k] = (bf16)((float)o[k] + (float)e[k]);   // the stored value + the embedding
-                }
             }
             wave_lds_fence();
 #pragma unroll
@@ -126,20 +129,15 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
                 const int px = i * 16 + sp;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * PT_SRS + sc8 * 16);
                 *reinterpret_cast<u32x4*>(ob + (long)(p * 32 + px) * PT_N + sc8 * 8) = v;
+                if (a.out2) {
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(&v), e = *reinterpret_cast<const bf16x8*>(&ev[i]);
+                    bf16x8 o2;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o2[c] = (bf16)((float)x[c] + (float)e[c]);   // the stored value + the embedding
+                    *reinterpret_cast<bf16x8*>(ob2 + (long)(p * 32 + px) * PT_N + sc8 * 8) = o2;
+                }
             }
             wave_lds_fence();
-            if (a.out2) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<bf16x4*>(stg + r * PT_SRS + (8 * g + 4 * h) * 2) = o2[g];
-                wave_lds_fence();
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int px = i * 16 + sp;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * PT_SRS + sc8 * 16);
-                    *reinterpret_cast<u32x4*>(ob2 + (long)(p * 32 + px) * PT_N + sc8 * 8) = v;
-                }
-                wave_lds_fence();
-            }
         }
     }
 }
@@ -158,6 +156,7 @@ static bool try_launch_point_bf16(const GemmPlan& P, const void* in, const void*
                                   hipStream_t st, const void* emb = nullptr, const int64_t* labels = nullptr,
                                   void* out2 = nullptr) {
     if (res || accumulate || out_f32 || !point_applicable(P)) return false;
+    if (out2 && (P.Hout * P.Wout) % 128) return false;     // the second output wants a tile inside one image
     PointArgs a;
     a.emb = (const bf16*)emb; a.labels = labels; a.out2 = (bf16*)out2; a.hw = P.Hout * P.Wout;
     a.in = (const bf16*)in; a.wp = (const bf16*)wp + P.ph[0].koff; a.out = (bf16*)out; a.scale = scale; a.shift = shift;
