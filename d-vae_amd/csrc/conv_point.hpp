@@ -1,35 +1,43 @@
-// 1x1 unit-stride convolution 256 -> 128 channels in bf16 (post_conv), weights resident in LDS.
+// 1x1 convolutions to 128 output channels in bf16, weights resident in LDS: post_conv (256 -> 128, unit stride) and
+// layer2's shortcut (64 -> 128, stride 2).
 //
-// The gather GEMM treats a 1x1 conv like any other: every 128 x 128 tile re-stages its 64 KB of weights and pays two
-// barriers per 64-deep K slab.  Here a persistent 512-thread workgroup per CU keeps the whole 128 x 256 weight matrix
-// in LDS (66 KB) and streams 128-pixel tiles of the input through a second 66 KB buffer: the next tile's rows are
-// fetched into registers while the current tile's 32 MFMAs per wave run, so a tile costs two barriers for 256 K-deep
+// The gather GEMM treats a 1x1 conv like any other: every 128 x 128 tile re-stages its weights and pays two
+// barriers per 64-deep K slab.  Here a persistent 512-thread workgroup keeps the whole 128 x CIN weight matrix
+// in LDS and streams 128-pixel tiles of the input through a second buffer: the next tile's rows are
+// fetched into registers while the current tile's MFMAs run, so a tile costs two barriers for CIN-deep
 // work.  A wave owns 64 pixels x 32 output channels (two MFMAs per K step share one weight fragment: 1.5 KB of LDS
-// reads per MFMA); results go through the wave's LDS patch and leave as 64-byte channel runs.
+// reads per MFMA); results go through the wave's LDS patch and leave as 64-byte channel runs.  With 256 input channels
+// the two buffers fill the LDS (one workgroup per CU); with 64 they take 58 KB and two workgroups share a CU.  The
+// strided variant reads every other pixel of every other row: whole 128-byte pixels, so no fetched byte is wasted.
 #pragma once
 #include "igemm.hpp"
 
 namespace dvae {
 
 struct PointArgs {
-    const bf16* in;            // [M][256]
+    const bf16* in;            // [M][CIN] (unit stride) or [B][SD ho][SD wo][CIN]
     const bf16* wp;            // packed rows [128][Ktot]
     bf16* out;                 // [M][128]
     const float* scale;        // per output channel or NULL (1)
     const float* shift;        // per output channel or NULL (0)
-    int relu, ntiles, Ktot;    // tiles of 128 pixels
+    int relu, ntiles, Ktot;    // tiles of 128 output pixels
     // optional second output: out2 = out + emb[labels[image]][pixel] (class embedding in activation layout, hw pixels per image)
     const bf16* emb;
     const int64_t* labels;
     bf16* out2;
     int hw;
+    int ho, wo, lho, lwo;      // strided variant: output height / width (powers of two) and their logs
 };
 
-constexpr int PT_CIN = 256, PT_N = 128, PT_RS = PT_CIN * 2 + 16, PT_VPP = PT_CIN / 8;   // padded row; 16-byte vectors per row
+constexpr int PT_N = 128;
 constexpr int PT_SRS = 32 * 2 + 16;                                                     // patch row: 32 channels + pad
-constexpr int PT_LDS = 2 * 128 * PT_RS + 8 * 32 * PT_SRS + 2 * PT_N * 4;
+template <int CIN>
+static constexpr int point_lds_bytes() { return 2 * 128 * (CIN * 2 + 16) + 8 * 32 * PT_SRS + 2 * PT_N * 4; }
 
+// SD: spatial stride of the gather (1, or 2 with Hout = Hin / 2)
+template <int CIN, int SD>
 __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a) {
+    constexpr int PT_CIN = CIN, PT_RS = CIN * 2 + 16, PT_VPP = CIN / 8;   // padded row; 16-byte vectors per row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wlds = smem;                          // [128 channels][PT_RS]
     unsigned char* xlds = smem + 128 * PT_RS;            // [128 pixels][PT_RS]
@@ -47,10 +55,19 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
         ssl[PT_N + tid] = a.shift ? a.shift[tid] : 0.f;
     }
     u32x4 xr[XV];
-    auto fetch = [&](int tile) {                          // a tile is 128 consecutive rows: 64 KB contiguous
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.in + (long)tile * 128 * PT_CIN);
+    auto fetch = [&](int tile) {
+        if (SD == 1) {                                    // a tile is 128 consecutive pixels: contiguous
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.in + (long)tile * 128 * PT_CIN);
 #pragma unroll
-        for (int k = 0; k < XV; ++k) xr[k] = src[tid + 512 * k];
+            for (int k = 0; k < XV; ++k) xr[k] = src[tid + 512 * k];
+        } else {                                          // output pixel (b, oy, ox) reads input pixel (b, SD oy, SD ox)
+#pragma unroll
+            for (int k = 0; k < XV; ++k) {
+                const int v = tid + 512 * k, m = tile * 128 + v / PT_VPP, cv = v % PT_VPP;
+                const int ox = m & (a.wo - 1), q = m >> a.lwo, oy = q & (a.ho - 1), b = q >> a.lho;
+                xr[k] = *reinterpret_cast<const u32x4*>(a.in + ((long)(b * a.ho * SD + oy * SD) * (a.wo * SD) + ox * SD) * PT_CIN + cv * 8);
+            }
+        }
     };
     auto wave_lds_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -142,29 +159,45 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
     }
 }
 
-static bool point_applicable(const GemmPlan& P) {
-    if (P.nphase != 1 || P.CgS != PT_CIN || P.N != PT_N || P.NS != PT_N) return false;
+// Geometry the kernel is built for: CIN 256 with unit stride, or CIN 64 with stride 2.  0: not applicable.
+static int point_cin(const GemmPlan& P) {
+    if (P.nphase != 1 || P.N != PT_N || P.NS != PT_N) return 0;
     const Phase& ph = P.ph[0];
-    if (ph.ntaps != 1 || ph.dy[0] || ph.dx[0] || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return false;
-    if (P.Hin != P.Hout || P.Win != P.Wout || ph.Hg != P.Hout || ph.Wg != P.Wout) return false;
+    if (ph.ntaps != 1 || ph.dy[0] || ph.dx[0] || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return 0;
+    if (ph.Hg != P.Hout || ph.Wg != P.Wout || ph.SY != ph.SX) return 0;
     const long M = (long)P.B * P.Hout * P.Wout;
-    return M % 128 == 0 && M * PT_CIN <= 0x7fffffffL;
+    if (M % 128 || M * 256 > 0x7fffffffL) return 0;
+    if (P.CgS == 256 && ph.SY == 1 && P.Hin == P.Hout && P.Win == P.Wout) return 256;
+    if (P.CgS == 64 && ph.SY == 2 && P.Hin == 2 * P.Hout && P.Win == 2 * P.Wout && ilog2_exact(P.Hout) >= 0 &&
+        ilog2_exact(P.Wout) >= 0)
+        return 64;
+    return 0;
 }
+static bool point_applicable(const GemmPlan& P) { return point_cin(P) != 0; }
 
 static bool try_launch_point_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                   const float* shift, const void* res, int relu, int accumulate, int out_f32,
                                   hipStream_t st, const void* emb = nullptr, const int64_t* labels = nullptr,
                                   void* out2 = nullptr) {
-    if (res || accumulate || out_f32 || !point_applicable(P)) return false;
-    if (out2 && (P.Hout * P.Wout) % 128) return false;     // the second output wants a tile inside one image
+    const int cin = point_cin(P);
+    if (res || accumulate || out_f32 || !cin) return false;
+    if (out2 && (cin != 256 || (P.Hout * P.Wout) % 128)) return false;   // the second output wants a tile inside one image
     PointArgs a;
     a.emb = (const bf16*)emb; a.labels = labels; a.out2 = (bf16*)out2; a.hw = P.Hout * P.Wout;
     a.in = (const bf16*)in; a.wp = (const bf16*)wp + P.ph[0].koff; a.out = (bf16*)out; a.scale = scale; a.shift = shift;
     a.relu = relu; a.ntiles = (int)((long)P.B * P.Hout * P.Wout / 128); a.Ktot = P.Ktot;
-    static LdsOptIn lds_opt;
-    lds_opt.ensure(reinterpret_cast<const void*>(&conv_point_bf16_kernel), PT_LDS);
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;
-    hipLaunchKernelGGL(conv_point_bf16_kernel, dim3(grid), dim3(512), PT_LDS, st, a);
+    a.ho = P.Hout; a.wo = P.Wout; a.lho = ilog2_exact(P.Hout); a.lwo = ilog2_exact(P.Wout);
+    if (cin == 256) {
+        static LdsOptIn lds_opt;
+        lds_opt.ensure(reinterpret_cast<const void*>(&conv_point_bf16_kernel<256, 1>), point_lds_bytes<256>());
+        const int grid = a.ntiles < 256 ? a.ntiles : 256;
+        hipLaunchKernelGGL((conv_point_bf16_kernel<256, 1>), dim3(grid), dim3(512), point_lds_bytes<256>(), st, a);
+    } else {
+        static LdsOptIn lds_opt;
+        lds_opt.ensure(reinterpret_cast<const void*>(&conv_point_bf16_kernel<64, 2>), point_lds_bytes<64>());
+        const int grid = a.ntiles < 512 ? a.ntiles : 512;   // two workgroups per CU
+        hipLaunchKernelGGL((conv_point_bf16_kernel<64, 2>), dim3(grid), dim3(512), point_lds_bytes<64>(), st, a);
+    }
     return true;
 }
 

@@ -158,7 +158,7 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
 int dvae_conv_supports_emb_out(const dvae_conv_desc* d, int dtype) {
     GemmPlan P;
     if (!d || dtype != DVAE_BF16 || build_plan(*d, DVAE_OP_FWD, dtype, P)) return 0;
-    return (point_applicable(P) && (P.Hout * P.Wout) % 128 == 0) ? 1 : 0;
+    return (point_cin(P) == 256 && (P.Hout * P.Wout) % 128 == 0) ? 1 : 0;
 }
 
 int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype) {
