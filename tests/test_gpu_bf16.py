@@ -207,6 +207,90 @@ def test_conv_bf16_fused_epilogue_and_accumulate(B, cin, cout, hin):
     assert rel_err(from_act(dxa, cin), want) < 6e-3
 
 
+PERSISTENT = [
+    # cin, cout, k, stride, pad, transposed, hin, epilogue ("plain" | "res": scale/shift + residual + ReLU | "f32": fp32 out)
+    (3, 64, 3, 1, 1, False, 32, "plain"),       # stem kernel
+    (64, 64, 3, 1, 1, False, 32, "plain"),      # halo kernel
+    (64, 64, 3, 1, 1, False, 32, "res"),        # halo kernel, residual + ReLU on the drain side
+    (64, 32, 3, 1, 1, True, 32, "plain"),       # halo kernel, 32 output channels
+    (32, 3, 3, 1, 1, True, 32, "f32"),          # halo kernel, fp32 output, two workgroups per CU
+    (64, 128, 1, 2, 0, False, 32, "plain"),     # weights-resident 1x1, stride 2
+    (256, 128, 1, 1, 0, False, 16, "plain"),    # weights-resident 1x1
+    (128, 64, 4, 2, 1, True, 16, "plain"),      # image-resident transposed conv
+    (128, 128, 3, 1, 1, False, 16, "res"),      # image-resident 3x3 with residual
+]
+
+
+@pytest.mark.parametrize("cfg", PERSISTENT, ids=lambda c: "-".join(str(v) for v in c))
+def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
+    """The specialised conv kernels are persistent: a workgroup walks many tiles (or images) of a large launch, with
+    the next tile prefetched and the previous one drained inside the current tile's loop.  The small-batch parity
+    tests give every workgroup at most one tile, so this one runs 800 images (3 to 13 tiles per workgroup) and
+    requires every image's output to equal, bit for bit, what a 3-image launch computes for it: a conv has no
+    cross-image term (resnet.py:26-31, :2139-2167), so any difference is a tile-loop hazard."""
+    cin, cout, k, stride, pad, tr, hin, mode = cfg
+    lib = L.lib()
+    B, b = 800, 3
+    g = torch.Generator().manual_seed(17 + cin + cout)
+    sp = ConvSpec("t", cin, cout, k, stride, pad, tr, hin, True)
+    w = torch.randn(sp.wshape, generator=g) / (cin * k * k) ** 0.5
+    ho = (hin - 1) * stride - 2 * pad + k if tr else (hin + 2 * pad - k) // stride + 1
+    f32out = mode == "f32"
+    cs_in, cs_out = L.act_channels(cin, L.BF16), L.act_channels(cout, L.F32 if f32out else L.BF16)
+    x = torch.randn(B, hin, hin, cs_in, generator=g).cuda().bfloat16()
+    if cs_in > cin:
+        x[..., cin:] = 0
+    res = torch.randn(B, ho, ho, cs_out, generator=g).cuda().bfloat16() if mode == "res" else None
+    sc = (torch.rand(cout, generator=g) + 0.5).cuda() if mode == "res" else None
+    sh = torch.randn(cout, generator=g).cuda()
+    st = L.stream()
+    odt = torch.float32 if f32out else torch.bfloat16
+
+    def run(lo, n):
+        d = L.ConvDesc(n, hin, hin, cin, cout, k, k, stride, pad, int(tr))
+        pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+        y = torch.full((n, ho, ho, cs_out), 3.0, device="cuda", dtype=odt)
+        ep = L.Epilogue(L.ptr(sc), sh.data_ptr(), None if res is None else res[lo:lo + n].data_ptr(), int(mode == "res"), int(f32out))
+        L.check(lib.dvae_conv_fwd(x[lo:lo + n].data_ptr(), pk.data_ptr(), C.byref(ep), y.data_ptr(), C.byref(d), L.BF16, st))
+        torch.cuda.synchronize()
+        return y
+
+    big = run(0, B)
+    assert torch.isfinite(big.float()).all()
+    for lo in (0, 398, B - b):
+        small = run(lo, b)
+        assert torch.equal(big[lo:lo + b, ..., :cout], small[..., :cout]), f"images {lo}..{lo + b - 1} differ"
+
+
+def test_fused_encoder_head_does_not_depend_on_the_batch():
+    """The fused head walks images with a persistent workgroup too, and its noise is keyed by the global image index
+    (resnet.py:2257-2259 draws per element): image i of an 800-image launch equals image i of a 3-image launch that
+    starts its numbering at i, bit for bit."""
+    lib = L.lib()
+    cin, h, Ld, B, b = 128, 16, 256, 800, 3
+    g = torch.Generator().manual_seed(23)
+    w = torch.randn(2 * Ld, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = (0.1 * torch.randn(2 * Ld, generator=g)).cuda()
+    x = torch.randn(B, h, h, cin, generator=g).cuda().bfloat16()
+    st = L.stream()
+
+    def run(lo, n):
+        d = L.ConvDesc(n, h, h, cin, 2 * Ld, 1, 1, 1, 0, 0)
+        pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+        z = torch.full((n, h, h, Ld), 7.0, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_fc_reparam_fwd_philox(x[lo:lo + n].data_ptr(), pk.data_ptr(), bias.data_ptr(), z.data_ptr(), C.byref(d),
+                                               Ld, None, 1000 + lo, 0xfeedbeef12345, 2, L.BF16, st))
+        torch.cuda.synchronize()
+        return z
+
+    big = run(0, B)
+    assert torch.isfinite(big.float()).all()
+    for lo in (0, 511, B - b):
+        assert torch.equal(big[lo:lo + b], run(lo, b)), f"images {lo}..{lo + b - 1} differ"
+
+
 @pytest.mark.parametrize("B,Ld", [(3, 256), (5, 128)])
 def test_fused_encoder_head_bf16(B, Ld):
     """fc_mu|fc_var (1x1 conv, resnet.py:2245-2246) + reparameterise (resnet.py:2257-2259) in one launch against
