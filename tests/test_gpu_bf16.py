@@ -263,6 +263,62 @@ def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
         assert torch.equal(big[lo:lo + b, ..., :cout], small[..., :cout]), f"images {lo}..{lo + b - 1} differ"
 
 
+BACKWARD = [
+    (64, 64, 3, 1, 1, False, 32),       # all-tap weight gradient; halo kernel as input-gradient
+    (64, 32, 3, 1, 1, True, 32),
+    (64, 128, 3, 2, 1, False, 32),      # slab weight gradient; image-resident input-gradient (9 slabs)
+    (128, 64, 4, 2, 1, True, 16),
+    (128, 128, 3, 1, 1, False, 16),
+]
+
+
+@pytest.mark.parametrize("cfg", BACKWARD, ids=lambda c: "-".join(str(v) for v in c))
+def test_backward_kernels_at_train_batch(cfg):
+    """Input- and weight-gradient kernels at the reference's batch of 128 per launch (configs/cifar10/resnet18DVAE.yaml;
+    384 here: three such batches), where their workgroups loop over many tiles: the input gradient of an image does
+    not depend on the batch (bit-exact against 3-image launches), and the weight / bias gradient is linear in the
+    batch (the 384-image launch against the sum of three 128-image launches, fp32 summation order apart: 1e-4)."""
+    cin, cout, k, stride, pad, tr, hin = cfg
+    lib = L.lib()
+    B, b = 384, 3
+    g = torch.Generator().manual_seed(29 + cin + cout + k)
+    sp = ConvSpec("t", cin, cout, k, stride, pad, tr, hin, True)
+    w = torch.randn(sp.wshape, generator=g) / (cin * k * k) ** 0.5
+    ho = (hin - 1) * stride - 2 * pad + k if tr else (hin + 2 * pad - k) // stride + 1
+    cs_in, cs_out = L.act_channels(cin, L.BF16), L.act_channels(cout, L.BF16)
+    x = torch.randn(B, hin, hin, cs_in, generator=g).cuda().bfloat16()
+    gy = torch.randn(B, ho, ho, cs_out, generator=g).cuda().bfloat16()
+    st = L.stream()
+
+    def dgrad(lo, n):
+        d = L.ConvDesc(n, hin, hin, cin, cout, k, k, stride, pad, int(tr))
+        pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_DGRAD), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_DGRAD, L.BF16, st))
+        dx = torch.full((n, hin, hin, cs_in), 3.0, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_conv_dgrad(gy[lo:lo + n].data_ptr(), pk.data_ptr(), dx.data_ptr(), 0, C.byref(d), L.BF16, st))
+        torch.cuda.synchronize()
+        return dx
+
+    def wgrad(lo, n):
+        d = L.ConvDesc(n, hin, hin, cin, cout, k, k, stride, pad, int(tr))
+        ws = torch.empty(lib.dvae_conv_wgrad_workspace_bytes(C.byref(d)) // 4 + 4, device="cuda")
+        dw = torch.full(sp.wshape, 9.0, device="cuda")
+        db = torch.full((cout,), 9.0, device="cuda")
+        L.check(lib.dvae_conv_wgrad(x[lo:lo + n].data_ptr(), gy[lo:lo + n].data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                    ws.numel() * 4, C.byref(d), L.BF16, st))
+        torch.cuda.synchronize()
+        return dw, db
+
+    big = dgrad(0, B)
+    assert torch.isfinite(big.float()).all()
+    for lo in (0, 190, B - b):
+        assert torch.equal(big[lo:lo + b, ..., :cin], dgrad(lo, b)[..., :cin]), f"input gradient of images {lo}.. differs"
+    dw, db = wgrad(0, B)
+    parts = [wgrad(lo, 128) for lo in (0, 128, 256)]
+    assert rel_err(dw.cpu(), sum(p_[0] for p_ in parts).cpu()) < 1e-4
+    assert rel_err(db.cpu(), sum(p_[1] for p_ in parts).cpu()) < 1e-4
+
+
 def test_fused_encoder_head_does_not_depend_on_the_batch():
     """The fused head walks images with a persistent workgroup too, and its noise is keyed by the global image index
     (resnet.py:2257-2259 draws per element): image i of an 800-image launch equals image i of a 3-image launch that
