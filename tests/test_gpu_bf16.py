@@ -115,14 +115,16 @@ def test_model_forward_bf16(train):
     assert l2_err(from_act(mulv[:4, :, :, 256:], 256), ref["log_var"]) < 6e-2
 
 
-def test_train_step_bf16_tracks_fp32():
-    """Losses and gradients of one step, bf16 engine vs the fp32 oracle (gate open, epoch 11, stage 1)."""
-    ocfg, eng, p = _engine(L.BF16, 8)
-    x, y, eps = O.make_inputs(ocfg, 8)
+@pytest.mark.parametrize("B", [8, 128])
+def test_train_step_bf16_tracks_fp32(B):
+    """Losses and gradients of one step, bf16 engine vs the fp32 oracle (gate open, epoch 11, stage 1); at 8 images
+    and at the reference's batch of 128 (configs/cifar10/resnet18DVAE.yaml), where the backward kernels loop over tiles."""
+    ocfg, eng, p = _engine(L.BF16, B)
+    x, y, eps = O.make_inputs(ocfg, B)
     info, grads, _ = O.train_step({k: v.clone() for k, v in p.items()}, ocfg, x, y, eps, {}, 11, 1)
     x0 = eng.input_from_nchw(x.cuda())
     e = eng.eps_from_nchw(eps.cuda())
-    eng.forward(x0, y.cuda(), e, 8, True)
+    eng.forward(x0, y.cuda(), e, B, True)
     eng.loss_sums()
     eng.loss_gate(11, 3.0, 0.01)
     eng.backward()
