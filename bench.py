@@ -100,6 +100,12 @@ def cpu_baseline(n_images, stage=1, S=32):
 
 def main():
     a = parse()
+    # DVAE_BENCH_WATCHDOG=<seconds>: a run that has not finished by then prints every thread's Python stack and exits
+    # (a hung collective or a kernel that never returns then names the line it sits on)
+    wd = float(os.environ.get("DVAE_BENCH_WATCHDOG", "0"))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,7 +187,17 @@ def main():
     if not a.no_train:
         Bt = a.train_batch
         eng.set_hyper(lr=5e-3, max_norm=5.0, grad_scale=1.0 / world, steps_done=0)
-        allreduce = (lambda t: dist.all_reduce(t)) if world > 1 else None
+        if world > 1 and backend == "nccl":
+            allreduce = lambda t: dist.all_reduce(t)      # noqa: E731  RCCL, on the card, ordered with the current stream
+        elif world > 1:
+            # rehearsal: gloo's own staging of device tensors stalls now and then when two ranks share one card; stage
+            # through the host here so that the run exercises the multi-rank logic and nothing else
+            def allreduce(t):
+                h = t.cpu()
+                dist.all_reduce(h)
+                t.copy_(h)
+        else:
+            allreduce = None
         idx = torch.randperm(n_local, device="cuda", dtype=torch.int64).to(torch.int32)
 
         def train_step(i):
