@@ -1,5 +1,5 @@
 #!/bin/bash
-# One round's evidence in one GPU call: the un-profiled bench line, a kernel trace with per-kernel statistics of the
+# The measurement evidence in one GPU call: the un-profiled bench line, a kernel trace with per-kernel statistics of the
 # same command, and the two counter passes (FETCH_SIZE, WRITE_SIZE) the HBM-traffic figure comes from.
 # Outputs land in gpurun_out/prof_<tag>/.
 set -e
