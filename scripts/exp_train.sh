@@ -1,5 +1,5 @@
 #!/bin/bash
-# train-step throughput with the tree's library and with scripts/exp_<tag>.so builds, alternating
+# train-step throughput with the tree's library ("base") and with scripts/exp_<tag>.so builds, alternating
 set -e
 cd $GRAFT_REPO_ROOT
 cp d-vae_amd/lib/libdvae_hip.so /tmp/exp_base.so
