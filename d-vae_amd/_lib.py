@@ -72,6 +72,7 @@ _SIGS = {
     "dvae_loss_gate": (C.c_int, [_P, _P, _D, _D, _D, _D, _F, _F, _I, _P]),
     "dvae_recon_loss_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dvae_purify_quant": (C.c_int, [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "dvae_poison_u8": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "dvae_sqnorm_partial": (C.c_int, [_P, _L, _P, _P]),
     "dvae_clip_adam": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
 }

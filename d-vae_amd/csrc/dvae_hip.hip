@@ -631,6 +631,16 @@ int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out, 
 }
 
 // ---------------------------------------------------------------------------------------------
+int dvae_poison_u8(const uint8_t* src, const float* pert, const int64_t* labels, const uint8_t* mask, uint8_t* dst,
+                   int64_t N, int HW, void* st) {
+    if (!src || !pert || !dst || N <= 0 || HW <= 0) DVAE_FAIL(DVAE_EINVAL, "poison_u8: null argument / empty");
+    hipLaunchKernelGGL(poison_u8_kernel, dim3(grid_for((long)N * HW)), dim3(256), 0, S(st), src, pert, labels, mask, dst,
+                       (long)N, HW);
+    DVAE_CHECK_LAUNCH("poison_u8");
+    return DVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 int dvae_sqnorm_partial(const float* g, int64_t n, float* partial, void* st) {
     if (n <= 0) DVAE_FAIL(DVAE_EINVAL, "sqnorm: empty");
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(DVAE_NPARTIAL), dim3(256), 0, S(st), g, (long)n, partial);

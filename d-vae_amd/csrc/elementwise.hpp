@@ -385,6 +385,31 @@ __global__ void purify_quant_kernel(const TA* a, int CSA, const float* b, int CS
 }
 
 // ------------------------------------------------------------------------------------------------
+// unlearnable-example ingress: data = uint8(clip(float(data) + clamp(255 * perturbation, -255, 255), 0, 255))
+// (PoisonCIFAR10, dataset.py:1235, :1287-1289).  perturbation is fp32 NCHW, one image per sample
+// (sample-wise) or per class (class-wise: row = label).  Every step is a separately rounded fp32
+// operation, as numpy / torch perform them: no fused multiply-add.
+// ------------------------------------------------------------------------------------------------
+__global__ void poison_u8_kernel(const uint8_t* src, const float* pert, const int64_t* labels, const uint8_t* mask,
+                                 uint8_t* dst, long N, int HW) {
+    const long total = N * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW;
+        const int px = (int)(i % HW);
+        const uint8_t* s = src + i * 3;
+        uint8_t* d = dst + i * 3;
+        if (mask && !mask[n]) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; continue; }
+        const long row = labels ? (long)labels[n] : n;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float noise = fminf(fmaxf(__fmul_rn(pert[(row * 3 + c) * HW + px], 255.f), -255.f), 255.f);
+            const float v = fminf(fmaxf(__fadd_rn((float)s[c], noise), 0.f), 255.f);
+            d[c] = (uint8_t)(int)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam over one flat fp32 bucket
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, long n, float* partial) {

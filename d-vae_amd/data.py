@@ -25,6 +25,7 @@ class ArrayDataset:
         self.data = data
         self.targets = np.asarray(targets, dtype=np.int64)
         self.transform = transform
+        self.version = 0            # bump after overwriting ``data`` in place: device-resident loaders refresh their copy
 
     def __len__(self):
         return self.data.shape[0]
@@ -39,6 +40,47 @@ class ArrayDataset:
 def synthetic_cifar(n=50000, size=32, classes=10, seed=0):
     rng = np.random.default_rng(seed)
     return ArrayDataset(rng.integers(0, 256, (n, size, size, 3), dtype=np.uint8), np.arange(n) % classes)
+
+
+def _upsample(a, size):
+    """[..., g, g, 3] -> [..., size, size, 3] by separable linear interpolation (numpy only)."""
+    g = a.shape[-3]
+    pos = (np.arange(size) + 0.5) * g / size - 0.5
+    i0 = np.clip(np.floor(pos).astype(int), 0, g - 1)
+    i1 = np.clip(i0 + 1, 0, g - 1)
+    w = np.clip(pos - i0, 0.0, 1.0).astype(np.float32)
+    a = a[..., i0, :, :] * (1 - w)[:, None, None] + a[..., i1, :, :] * w[:, None, None]
+    return a[..., :, i0, :] * (1 - w)[:, None] + a[..., :, i1, :] * w[:, None]
+
+
+def synthetic_separable(n=50000, size=32, classes=10, seed=0, template_seed=1234, clutter=0.25, noise=0.05):
+    """A class-separable stand-in for CIFAR (no dataset can be fetched here): every class has a fixed smooth colour
+    template (shared by train and test sets through ``template_seed``); an image is its class template at a random
+    contrast plus a smooth random clutter field and pixel noise.  A ResNet-18 learns it in a few epochs, and a
+    class-wise additive pattern of a few grey levels is an easier shortcut than the templates -- which is what makes an
+    unlearnable-example poison work."""
+    trng = np.random.default_rng(template_seed)
+    templates = _upsample(trng.uniform(0.1, 0.9, (classes, 4, 4, 3)).astype(np.float32), size)
+    rng = np.random.default_rng(seed)
+    y = (np.arange(n) % classes).astype(np.int64)
+    out = np.empty((n, size, size, 3), dtype=np.uint8)
+    for lo in range(0, n, 4096):
+        hi = min(n, lo + 4096)
+        m = hi - lo
+        contrast = rng.uniform(0.6, 1.0, (m, 1, 1, 1)).astype(np.float32)
+        field = _upsample(rng.uniform(-1, 1, (m, 4, 4, 3)).astype(np.float32), size) * clutter
+        img = templates[y[lo:hi]] * contrast + field + rng.normal(0, noise, (m, size, size, 3)).astype(np.float32)
+        out[lo:hi] = (np.clip(img, 0, 1) * 255).astype(np.uint8)
+    return ArrayDataset(out, y)
+
+
+def synthetic_classwise_poison(classes=10, size=32, eps=8.0 / 255, seed=0):
+    """A class-wise shortcut perturbation in the ``perturbation.pt`` layout ([classes,3,H,W] float, values +-eps): a
+    random +-eps pattern on an 8x8 grid per class, as error-minimising noise is up to its L-inf bound."""
+    rng = np.random.default_rng(seed)
+    g = rng.choice([-1.0, 1.0], (classes, 3, 8, 8)).astype(np.float32)
+    p = np.kron(g, np.ones((size // 8, size // 8), dtype=np.float32))
+    return torch.from_numpy(p * eps)
 
 
 class DeviceLoader:
@@ -58,8 +100,9 @@ class DeviceLoader:
 
     def resident(self):
         """(uint8 [N,H,W,3], int64 [N]) device copies, refreshed if the host array was replaced."""
-        if self._dev_data is None or self._src is not self.dataset.data:
-            self._src = self.dataset.data
+        ver = getattr(self.dataset, "version", 0)      # bumped by whoever overwrites dataset.data in place
+        if self._dev_data is None or self._src is not self.dataset.data or self._ver != ver:
+            self._src, self._ver = self.dataset.data, ver
             self._dev_data = torch.from_numpy(self.dataset.data).to(self.device)
             self._dev_targets = torch.from_numpy(self.dataset.targets).to(self.device)
         return self._dev_data, self._dev_targets
@@ -95,6 +138,58 @@ class DeviceLoader:
             x = data[idx].permute(0, 3, 1, 2).float().div_(255)
             yield x, targets[idx]
         self.epoch += 1
+
+
+def poison_dataset(dataset: ArrayDataset, perturbation: torch.Tensor, perturb_type="samplewise", poison_rate=1.0, seed=0,
+                   poison_samples_idx=None, device="cuda"):
+    """Apply unlearnable-example noise to a uint8 set the way ``PoisonCIFAR10.__init__`` does
+    (dataset.py:1231-1289): ``data = uint8(clip(float32(data) + clamp(255 * perturbation, -255, 255), 0, 255))`` for the
+    selected samples, with ``perturbation`` the float tensor of ``perturbation.pt`` ([N,3,H,W] sample-wise or
+    [classes,3,H,W] class-wise, full-image noise).  The arithmetic runs on the device (libdvae_hip, bit-exact against
+    numpy's); ``dataset.data`` is overwritten in place.  Returns the sorted indices of the poisoned samples
+    (``poison_samples_idx``; with ``poison_rate`` < 1 they are drawn without replacement from a generator seeded with
+    ``seed``, not from numpy's global state as the reference does)."""
+    from . import _lib as L
+    n, H, W, _ = dataset.data.shape
+    pert = perturbation.detach().to(torch.float32)
+    if pert.dim() != 4 or tuple(pert.shape[1:]) != (3, H, W):
+        raise ValueError(f"perturbation must be [rows,3,{H},{W}] (full-image noise), got {tuple(pert.shape)}")
+    rows = pert.shape[0]
+    if perturb_type == "samplewise":
+        if rows != n:
+            raise ValueError("Poison Perturb Tensor size not match for samplewise")
+    elif perturb_type == "classwise":
+        if rows <= int(dataset.targets.max()):
+            raise ValueError("Poison Perturb Tensor size not match for classwise")
+    else:
+        raise ValueError("perturb_type must be 'samplewise' or 'classwise'")
+    if poison_samples_idx is None:
+        k = int(n * poison_rate)
+        if k >= n:
+            poison_samples_idx = np.arange(n)
+        else:
+            poison_samples_idx = np.sort(np.random.default_rng(seed).choice(n, k, replace=False))
+    poison_samples_idx = np.asarray(poison_samples_idx, dtype=np.int64)
+    dev = torch.device(device)
+    d = torch.from_numpy(dataset.data).to(dev)
+    mask = None
+    if poison_samples_idx.size != n:
+        mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+        mask[torch.from_numpy(poison_samples_idx).to(dev)] = 1
+    labels = torch.from_numpy(dataset.targets).to(dev) if perturb_type == "classwise" else None
+    pd = pert.contiguous().to(dev)
+    L.check(L.lib().dvae_poison_u8(L.ptr(d), L.ptr(pd), L.ptr(labels), L.ptr(mask), L.ptr(d), n, H * W, L.stream()))
+    dataset.data[...] = d.cpu().numpy()
+    dataset.version = getattr(dataset, "version", 0) + 1
+    dataset.poison_samples_idx = poison_samples_idx.tolist()
+    return dataset.poison_samples_idx
+
+
+def load_purified_numpy(root: str, prefix="cifar10", transform=None):
+    """Read back a set saved by ``save_purified_numpy`` (the files ``CIFAR10_numpy`` loads, dataset.py:1048-1049)."""
+    data = np.load(os.path.join(root, f"{prefix}_data.npy"))            # allow_pickle stays False
+    targets = np.load(os.path.join(root, f"{prefix}_target.npy"))
+    return ArrayDataset(data, targets, transform)
 
 
 class DatasetGenerator:

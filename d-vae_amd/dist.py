@@ -85,3 +85,31 @@ def all_gather_shards(local: torch.Tensor, n: int) -> torch.Tensor:
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n]
+
+
+def gather_shards(local: torch.Tensor, n: int, dst: int = 0):
+    """Like ``all_gather_shards`` but only rank ``dst`` receives the [n, ...] tensor (the others get None): for
+    results only one rank consumes, such as the perturbations rank 0 saves (main_vae_disentangle.py:91-92).  The
+    other ranks neither allocate nor receive the full tensor."""
+    rank, world = world_info()
+    if world == 1:
+        assert local.shape[0] == n
+        return local
+    per = (n + world - 1) // world
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    local = local.contiguous()
+    if rank == dst:
+        out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.gather(local, list(out.split(per, 0)), dst=dst)
+        return out[:n]
+    dist.gather(local, None, dst=dst)
+    return None
+
+
+def broadcast_(t: torch.Tensor, src: int = 0):
+    """In-place broadcast from rank ``src`` (identity on one process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src)
+    return t

@@ -488,13 +488,16 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
-    def forward(self, x0, y, eps, b, train: bool, need_rec: bool = True):
+    def forward(self, x0, y, eps, b, train: bool, need_rec: bool = True, need_mulv: bool | None = None):
         """x0: input act [B,S,S,4]; y: int64 [b]; eps: fp32 act [B,h,h,L].  Leaves rec_pre / p (and
         every intermediate needed by backward) in the engine's buffers and returns them.
         ``need_rec=False`` (inference only) leaves the reconstruction branch out and returns (None, p): for callers
-        that read nothing but the perturbation of this pass (main_vae_disentangle.py:61-62)."""
+        that read nothing but the perturbation of this pass (main_vae_disentangle.py:61-62).
+        ``need_mulv`` (default: training only): mu | log_var are written to the "mulv" buffer (fp32; "mulv.act" in
+        the act dtype for bf16 inference with in-kernel noise).  Without it the inference head may keep them in
+        registers, and those buffers then hold whatever an earlier call left."""
         stem_out = self.stem(x0, b, train)
-        _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train, y=y)
+        _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train if need_mulv is None else need_mulv, y=y)
         if isinstance(eps, PhiloxEps):
             eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
         rec_pre = self._decoder("decoder", z, b, train) if (train or need_rec) else None

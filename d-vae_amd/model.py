@@ -15,6 +15,8 @@ as stock torch modules and is evaluated only when ``compute_logits`` is set.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -63,7 +65,8 @@ class _PathFunction(torch.autograd.Function):
         e = eng.eps_from_nchw(eps) if eps is not None else eng.eps_philox(b, first=model._draws * b, stream_id=7)
         model._draws += 1
         train = model.training
-        rec_pre, p = eng.forward(x0, y, e, b, train)
+        # mu / log_var are returned to the caller: they must be written (the fused inference head keeps them in registers)
+        rec_pre, p = eng.forward(x0, y, e, b, train, need_mulv=True)
         S, h, Ld = eng.S, eng.h, eng.Ld
         rec_act = eng.buf("rec", (eng.B, S, S, 4), torch.float32)
         L.check(eng.lib.dvae_recon_loss_fwd(L.ptr(rec_pre), L.ptr(p), L.ptr(x0), L.ptr(rec_act), L.ptr(eng.recon_partial),
@@ -113,8 +116,23 @@ class _PathFunction(torch.autograd.Function):
         return None, None, None, None, torch.zeros_like(model._anchor)
 
 
+def _dtype_code(d):
+    """"f32" / "bf16" (or the library's DVAE_F32 / DVAE_BF16 codes) -> library code."""
+    if d in (L.F32, L.BF16) and not isinstance(d, str):
+        return int(d)
+    try:
+        return {"f32": L.F32, "fp32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}[str(d).lower()]
+    except KeyError:
+        raise ValueError(f"act_dtype must be 'f32' or 'bf16', got {d!r}") from None
+
+
 class ResNetDVAE(nn.Module):
-    def __init__(self, num_blocks=(2, 2, 2, 2), num_classes=10, stem_end_block=13, latent_dim=128):
+    """``act_dtype`` (not in the reference, which is fp32 throughout) selects the arithmetic of the path: "f32" = exact
+    fp32 MFMA, "bf16" = bf16 activations / packed weights with fp32 accumulation, statistics, losses, master
+    parameters and optimiser state.  It can also be set as an attribute at any time before the next call; the
+    environment variable DVAE_ACT_DTYPE overrides the constructor default."""
+
+    def __init__(self, num_blocks=(2, 2, 2, 2), num_classes=10, stem_end_block=13, latent_dim=128, act_dtype=None):
         super().__init__()
         if stem_end_block not in (7, 9):
             raise ValueError("stem_end_block must be 7 or 9: the reference's other values do not build a working D-VAE "
@@ -150,9 +168,10 @@ class ResNetDVAE(nn.Module):
         self.decoder_p = nn.Sequential(self.decoder_p1, self.decoder_p2, self.decoder_p3)
         # engine state (not part of state_dict)
         self.compute_logits = False
-        self.act_dtype = L.F32
+        self.act_dtype = _dtype_code(act_dtype if act_dtype is not None else os.environ.get("DVAE_ACT_DTYPE", "f32"))
         self.image_size = 32
         self._engine = None
+        self._versions = None
         self._draws = 0
         self._accumulate = False
         # a plain (unregistered) leaf that makes autograd record the path node even though the path's
@@ -183,15 +202,32 @@ class ResNetDVAE(nn.Module):
             raise RuntimeError("the D-VAE hot path runs on libdvae_hip (MI355X) only; move the model and inputs to the GPU")
         b, S = x.shape[0], x.shape[-1]
         eng = self._engine
+        dtype = _dtype_code(self.act_dtype)
         ok = (eng is not None and eng.B >= b and eng.S == S and eng.dev == x.device and eng.cfg == self._cfg_for(S)
-              and eng.dtype == self.act_dtype and self.conv1.weight.data_ptr() == eng.param["conv1.weight"].data_ptr())
+              and eng.dtype == dtype and self.conv1.weight.data_ptr() == eng.param["conv1.weight"].data_ptr())
         if ok:
+            # Parameters / BatchNorm buffers written behind the engine's back (load_state_dict, a stock optimiser's
+            # step, an in-place edit) bump their tensors' version counters: the packed weights and the folded
+            # BatchNorm are re-made when any of them moved since the last call.
+            v = self._path_versions()
+            if v != self._versions:
+                eng.invalidate()
+                self._versions = v
             return eng
         self.image_size = S
         cfg = self._cfg_for(S)
         old = {k: v.detach().clone() for k, v in self._named_path_tensors().items()}
-        eng = DVAEEngine(cfg, max(b, eng.B if eng is not None else 0), x.device, self.act_dtype)
+        prev = eng
+        eng = DVAEEngine(cfg, max(b, prev.B if prev is not None else 0), x.device, dtype,
+                         seed=prev.seed if prev is not None else 0)
         eng.load_params(old, strict=True)
+        if prev is not None and prev.nparam == eng.nparam and prev.dev == eng.dev and prev.cfg == cfg:
+            # a resize or a dtype change in the middle of a run keeps the optimiser going: Adam moments, the step
+            # count and the hyper-parameters live in the engine
+            eng.M.copy_(prev.M)
+            eng.V.copy_(prev.V)
+            eng.hyper.copy_(prev.hyper)
+            eng._hyper_host.copy_(prev._hyper_host)
         named_p = dict(self.named_parameters())
         for name, _ in param_layout(cfg):
             prm = named_p[name]
@@ -208,7 +244,22 @@ class ResNetDVAE(nn.Module):
             m._buffers["num_batches_tracked"] = self._nbt[i]
         self._engine = eng
         self._accumulate = False
+        self._versions = self._path_versions()
         return eng
+
+    def _path_versions(self):
+        named = self._named_path_tensors()
+        return tuple(named[n]._version for n in self._path_names())
+
+    def _path_names(self):
+        names = getattr(self, "_path_names_cache", None)
+        if names is None or names[0] != self._cfg_for(self.image_size):
+            cfg = self._cfg_for(self.image_size)
+            ns = [n for n, _ in param_layout(cfg)]
+            for n, _ in bn_names(cfg):
+                ns += [n + ".running_mean", n + ".running_var"]
+            names = self._path_names_cache = (cfg, ns)
+        return names[1]
 
     def _cfg_for(self, S):
         c = self.engine_config()
@@ -291,6 +342,7 @@ class ResNetDVAE(nn.Module):
         return self.linear(self.pooling(x).flatten(1))
 
 
-def ResNet18DVAE(num_classes=10, stem_end_block=15, latent_dim=128):
-    """Factory with the reference's signature (resnet.py:2261-2262)."""
-    return ResNetDVAE((2, 2, 2, 2), num_classes=num_classes, stem_end_block=stem_end_block, latent_dim=latent_dim)
+def ResNet18DVAE(num_classes=10, stem_end_block=15, latent_dim=128, act_dtype=None):
+    """Factory with the reference's signature (resnet.py:2261-2262) plus ``act_dtype`` ("f32" | "bf16")."""
+    return ResNetDVAE((2, 2, 2, 2), num_classes=num_classes, stem_end_block=stem_end_block, latent_dim=latent_dim,
+                      act_dtype=act_dtype)

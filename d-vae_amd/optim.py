@@ -29,7 +29,7 @@ class FusedAdam(torch.optim.Optimizer):
         if eng is None:
             raise RuntimeError("FusedAdam.step() before any forward/backward on the GPU")
         g = self.param_groups[0]
-        key = (g["lr"], g["betas"], g["eps"], self.max_norm, grad_scale)
+        key = (id(eng), g["lr"], g["betas"], g["eps"], self.max_norm, grad_scale)
         if key != self._pushed:
             eng.set_hyper(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], max_norm=self.max_norm,
                           grad_scale=grad_scale)

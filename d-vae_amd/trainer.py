@@ -66,21 +66,22 @@ _METERS = ("loss", "loss_rec", "loss_rec_p", "loss_p", "loss_cls", "loss_cls_p",
 
 class VAE_Trainer:
     def __init__(self, data_loader, logger, config, global_step=0, target="train_dataset", stage=0, kd=2.5,
-                 monitor_every=None):
+                 monitor_every=None, act_dtype=None):
         self.data_loader, self.logger, self.config = data_loader, logger, config
+        self.act_dtype = act_dtype          # None: whatever the model was built with; "f32" | "bf16" sets model.act_dtype
         lf = getattr(config, "log_frequency", None)
         self.log_frequency = lf if lf is not None else 100
         self.global_step, self.target = global_step, target
         self.stage, self.kd = stage, kd
         self.monitor_every = self.log_frequency if monitor_every is None else monitor_every
         self._monitors = {k: 0.0 for k in ("loss_cls", "loss_cls_p", "loss_cls_p2", "loss_cls_purified")}
+        self._monitor_fresh, self._monitor_n = False, 0
         self._reset_stats()
 
     def _reset_stats(self):
         for k in _METERS:
             setattr(self, k + "_meters", AverageMeter())
-        self._dev_sum = None
-        self._dev_n = 0
+        self._pending = []          # per-step (device scalars, batch size) since the last host sync
 
     # -- epoch loop (main_vae_disentangle.py:162-178) ------------------------------------------------
     def train(self, epoch, model, model_c, optimizer):
@@ -100,6 +101,8 @@ class VAE_Trainer:
 
     # -- one step (main_vae_disentangle.py:180-250) --------------------------------------------------
     def train_batch(self, images, labels, model, model_c, optimizer, epoch):
+        if self.act_dtype is not None:
+            model.act_dtype = self.act_dtype
         target, weight = stage_constants(self.stage, self.kd)
         grad_clip = getattr(self.config, "grad_clip", 5.0)
         if isinstance(optimizer, FusedAdam):
@@ -116,9 +119,7 @@ class VAE_Trainer:
             loss = loss + max(loss_p, 0.002)
         loss.backward()
         grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
-        optimizer.step()
-        if getattr(model, "_engine", None) is not None:
-            model._engine.invalidate()
+        optimizer.step()            # the model notices the in-place update (tensor versions) and re-packs its weights
         self._monitor(images, labels, rec.detach(), perturbation.detach(), model_c)
         vals = dict(loss=loss.item(), loss_rec=loss_rec.item(), loss_rec_p=loss_rec_p.item(), loss_p=loss_p.item(),
                     kld_loss=kld_loss.item())
@@ -130,7 +131,7 @@ class VAE_Trainer:
         b = images.shape[0]
         optimizer.max_norm = grad_clip
         g = optimizer.param_groups[0]
-        key = (g["lr"], g["betas"], g["eps"], grad_clip, 1.0 / world)
+        key = (id(eng), g["lr"], g["betas"], g["eps"], grad_clip, 1.0 / world)
         if key != optimizer._pushed:
             eng.set_hyper(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], max_norm=grad_clip,
                           grad_scale=1.0 / world)
@@ -147,9 +148,27 @@ class VAE_Trainer:
             self._monitor(images, labels, rec, pert, model_c, force=True)
         # statistics stay on the device; materialize() syncs once, at log time
         s = eng.scal.clone()
-        self._dev_sum = s if self._dev_sum is None else self._dev_sum + s
-        self._dev_n += 1
+        self._pending.append((s, b))
+        if len(self._pending) >= 1024:          # nobody is logging: fold now and then so the list stays short
+            self._fold_pending()
         return {"_scal": s, "_n": b, "_lr": g["lr"]}
+
+    def _fold_pending(self):
+        """Feed the per-step scalars kept on the device since the last sync into the meters, step by step and
+        weighted by each step's batch size, exactly as the reference's per-step ``.item()`` updates do
+        (main_vae_disentangle.py:215-225)."""
+        if not self._pending:
+            return
+        rows = torch.stack([s for s, _ in self._pending]).cpu().numpy()
+        for r, (_, n) in zip(rows, self._pending):
+            vals = {"loss": float(r[L.SCAL["loss"]]), "loss_rec": float(r[L.SCAL["loss_rec"]]),
+                    "loss_rec_p": float(r[L.SCAL["loss_rec_p"]]), "loss_p": float(r[L.SCAL["loss_p"]]),
+                    "kld_loss": float(r[L.SCAL["kld"]])}
+            vals["psnr"] = -10 * math.log10(max(vals["loss_rec"], 1e-30))
+            vals["psnr_p"] = -10 * math.log10(max(vals["loss_rec_p"], 1e-30))
+            for k, v in vals.items():
+                getattr(self, k + "_meters").update(v, n)
+        self._pending = []
 
     @torch.no_grad()
     def _monitor(self, images, labels, rec, pert, model_c, force=False):
@@ -167,6 +186,7 @@ class VAE_Trainer:
         self._monitors["loss_cls_p2"] = F.cross_entropy(lg[2 * b:], labels).item()
         uni = torch.ones_like(lg[2 * b:]) / lg.shape[1]
         self._monitors["loss_cls_purified"] = F.kl_div(F.log_softmax(lg[2 * b:], dim=1), uni, reduction="batchmean").item()
+        self._monitor_fresh, self._monitor_n = True, b
 
     def materialize(self, payload):
         """Turn a fused-step payload into the reference's 24-key dict (one device->host copy)."""
@@ -175,12 +195,7 @@ class VAE_Trainer:
         s = payload["_scal"].cpu().numpy()
         vals = dict(loss=float(s[L.SCAL["loss"]]), loss_rec=float(s[L.SCAL["loss_rec"]]), loss_rec_p=float(s[L.SCAL["loss_rec_p"]]),
                     loss_p=float(s[L.SCAL["loss_p"]]), kld_loss=float(s[L.SCAL["kld"]]))
-        if self._dev_sum is not None:
-            # fold the device-side sums of the steps since the last sync into the meters
-            tot = self._dev_sum.cpu().numpy() / max(1, self._dev_n)
-            for k, i in (("loss", "loss"), ("loss_rec", "loss_rec"), ("loss_rec_p", "loss_rec_p"), ("loss_p", "loss_p"), ("kld_loss", "kld")):
-                getattr(self, k + "_meters").update(float(tot[L.SCAL[i]]), payload["_n"] * self._dev_n)
-            self._dev_sum, self._dev_n = None, 0
+        self._fold_pending()
         return self._payload(vals, 0, None, float(s[L.SCAL["grad_norm"]]), lr=payload["_lr"])
 
     def _payload(self, vals, n, optimizer, grad_norm, lr=None):
@@ -190,6 +205,13 @@ class VAE_Trainer:
         if n:
             for k in _METERS:
                 getattr(self, k + "_meters").update(vals[k], n)
+        else:
+            # fused route: the loss / psnr meters were fed step by step from the device scalars; the monitor
+            # losses are host floats already
+            for k in ("loss_cls", "loss_cls_p", "loss_cls_p2", "loss_cls_purified"):
+                if self._monitor_fresh:
+                    getattr(self, k + "_meters").update(vals[k], self._monitor_n)
+            self._monitor_fresh = False
         out = {}
         for k in ("psnr", "psnr_p", "loss", "loss_rec", "loss_rec_p", "loss_p", "loss_cls", "loss_cls_p", "loss_cls_p2",
                   "loss_cls_purified", "kld_loss"):
@@ -201,16 +223,24 @@ class VAE_Trainer:
 
 
 @torch.no_grad()
-def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 0, device="cuda"):
+def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 0, device="cuda", act_dtype=None,
+                   timings: dict | None = None):
     """The epoch-0 branch of ``Trainer.train`` (main_vae_disentangle.py:59-69) for a whole dataset:
     overwrites ``dataset.data`` in place with the purified uint8 images and returns the recorded
-    perturbations as a float64 tensor [N,3,H,W].  Images are sharded over ranks by contiguous index
-    range and all-gathered at the end; the reparameterisation noise is keyed by global image index, so
-    the result does not depend on the world size or the batch size."""
+    perturbations as a float64 tensor [N,3,H,W] (on rank 0; the other ranks, which do not save it, get None).
+    Images are sharded over ranks by contiguous index range; the uint8 shards are all-gathered at the end (every
+    rank trains the next stage on the full purified set), the perturbations are gathered to rank 0 only.  The
+    reparameterisation noise is keyed by global image index, so the result does not depend on the world size or the
+    batch size.  BatchNorm running statistics are taken from rank 0 (``DataParallel`` keeps replica 0's,
+    main_vae_disentangle.py:426-428), so every shard is purified by the same function.
+    ``timings`` (optional dict) receives the wall time of each phase in seconds."""
     rank, world = D.world_info()
+    t0 = time.perf_counter()
     n = len(dataset)
     lo, hi = D.shard_range(n, rank, world)
     dev = torch.device(device)
+    if act_dtype is not None:
+        model_s.act_dtype = act_dtype
     data = torch.from_numpy(dataset.data[lo:hi]).to(dev)
     labels = torch.from_numpy(np.asarray(dataset.targets[lo:hi], dtype=np.int64)).to(dev)
     S = dataset.data.shape[1]
@@ -218,17 +248,34 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 
     model_s.eval()
     probe = torch.zeros(min(batch, max(1, hi - lo)), 3, S, S, device=dev)
     eng = model_s._engine_for(probe)
+    if world > 1:
+        D.broadcast_(eng.R, 0)
+        eng.fold_valid = False
     eng.seed = seed
     out = torch.empty_like(data)
     noise = torch.empty(hi - lo, 3, S, S, device=dev)
+    if timings is not None:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
     for first in range(0, hi - lo, eng.B):
         b = min(eng.B, hi - lo - first)
         eng.purify_batch(data, out, noise, labels, first, b, stage, global_first=lo + first)
+    if timings is not None:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
     full_u8 = D.all_gather_shards(out, n)
-    full_noise = D.all_gather_shards(noise, n)
+    full_noise = D.gather_shards(noise, n, dst=0)
+    if timings is not None:
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
     dataset.data[...] = full_u8.cpu().numpy()
+    dataset.version = getattr(dataset, "version", 0) + 1      # loaders holding a device copy refresh it
     model_s.train(was_training)
-    return full_noise.cpu().to(torch.float64)
+    res = full_noise.cpu().to(torch.float64) if full_noise is not None else None
+    if timings is not None:
+        t4 = time.perf_counter()
+        timings.update(upload_s=t1 - t0, kernels_s=t2 - t1, gather_s=t3 - t2, host_tail_s=t4 - t3, total_s=t4 - t0)
+    return res
 
 
 class Trainer:
@@ -236,13 +283,13 @@ class Trainer:
     train the classifier on the purified set with stock torch ops (not on the accelerated path)."""
 
     def __init__(self, criterion, data_loader, logger, config, global_step=0, target="train_dataset",
-                 datasets_generator=None, exp_name=".", iters=0, purify_batch=1024, seed=0):
+                 datasets_generator=None, exp_name=".", iters=0, purify_batch=1024, seed=0, act_dtype=None):
         self.criterion, self.data_loader, self.logger, self.config = criterion, data_loader, logger, config
         lf = getattr(config, "log_frequency", None)
         self.log_frequency = lf if lf is not None else 100
         self.global_step, self.target = global_step, target
         self.datasets_generator, self.exp_name, self.iters = datasets_generator, exp_name, iters
-        self.purify_batch, self.seed = purify_batch, seed
+        self.purify_batch, self.seed, self.act_dtype = purify_batch, seed, act_dtype
         self.train_transform = "crop_flip"   # RandomCrop(32, 4) + HorizontalFlip + ToTensor (:85-87)
         self._reset_stats()
 
@@ -257,7 +304,7 @@ class Trainer:
         if epoch == 0:
             if model_s is not None:
                 ds = self.datasets_generator.datasets["train_dataset"]
-                noise = purify_dataset(model_s, ds, self.iters, self.purify_batch, self.seed)
+                noise = purify_dataset(model_s, ds, self.iters, self.purify_batch, self.seed, act_dtype=self.act_dtype)
                 ds.transform = self.train_transform
                 self.data_loader = self.datasets_generator.getDataLoader()
                 rank, _ = D.world_info()
@@ -279,17 +326,27 @@ class Trainer:
         return self.global_step
 
     def train_batch(self, images, labels, model, optimizer):
-        """:97-125, CrossEntropyLoss criterion (the D-VAE configs' only one)."""
+        """:97-125, CrossEntropyLoss criterion (the D-VAE configs' only one).  With more than one process the gradients
+        are averaged over ranks through one flat bucket before the clip (the mean of per-rank batch means = the
+        global-batch mean for equal per-rank batches)."""
+        from .classifier import DataParallelSGD, accuracy
         model.zero_grad()
         optimizer.zero_grad()
         logits = model(images)
         loss = self.criterion(logits, labels)
         loss.backward()
+        if getattr(self, "_dp", None) is None:
+            self._dp = DataParallelSGD()
+        self._dp.sync(model)
         grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), getattr(self.config, "grad_clip", 5.0))
         optimizer.step()
-        acc = (logits.argmax(1) == labels).float().mean().item()
+        if logits.shape[1] >= 5:
+            acc, acc5 = (a.item() for a in accuracy(logits, labels, topk=(1, 5)))
+        else:
+            acc, acc5 = accuracy(logits, labels, topk=(1,))[0].item(), 1
         self.loss_meters.update(loss.item(), labels.shape[0])
         self.acc_meters.update(acc, labels.shape[0])
+        self.acc5_meters.update(acc5, labels.shape[0])
         return {"acc": acc, "acc_avg": self.acc_meters.avg, "loss": loss.item(), "loss_avg": self.loss_meters.avg,
                 "lr": optimizer.param_groups[0]["lr"], "|gn|": float(grad_norm)}
 

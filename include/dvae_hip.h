@@ -232,6 +232,15 @@ int dvae_recon_loss_bwd(const float* rec, const float* p, const void* x, const f
 int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out /* or NULL */,
                       uint8_t* out_u8_nhwc /* or NULL */, int64_t first, int B, int HW, int dtype, void* stream);
 
+/* ---- unlearnable-example ingress (PoisonCIFAR10, dataset.py:1235, :1287-1289) ------------------
+ * dst = uint8(clip(float(src) + clamp(255 * perturbation, -255, 255), 0, 255)) on uint8 NHWC images, every step one
+ * rounded fp32 operation as numpy performs it (bit-exact against the reference's arithmetic).  perturbation is fp32
+ * NCHW [rows][3][HW]: row = image index (sample-wise, labels == NULL) or row = labels[image] (class-wise).
+ * mask (uint8 [N], or NULL = all) selects the poisoned images (poison_rate < 1); the others are copied.
+ * dst may alias src. */
+int dvae_poison_u8(const uint8_t* src_u8_nhwc, const float* perturbation_nchw, const int64_t* labels /* or NULL */,
+                   const uint8_t* mask /* or NULL */, uint8_t* dst_u8_nhwc, int64_t N, int HW, void* stream);
+
 /* ---- clip_grad_norm_ + Adam (main_vae_disentangle.py:210-211, resnet18DVAE.yaml:21-23) -------
  * hyper (device, fp32[8]): lr, beta1, beta2, eps, max_norm, grad_scale, steps_done, unused;
  * steps_done is incremented on the device after the update (graph-replay friendly).

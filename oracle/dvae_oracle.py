@@ -329,6 +329,40 @@ def train_step(p, cfg, x, y, eps, adam_state, epoch, stage, kd=3.0, lr=5e-3, gra
     return info, grads, {k: v.detach() for k, v in out.items()}
 
 
+def train_step_data_parallel(p, cfg, x, y, eps, adam_state, epoch, stage, world, kd=3.0, lr=5e-3, grad_clip=5.0,
+                             masks=None):
+    """One VAE_Trainer.train_batch as ``torch.nn.DataParallel`` over ``world`` replicas runs it
+    (main_vae_disentangle.py:426-428): the batch is scattered in contiguous chunks, every replica normalises with the
+    BatchNorm statistics of ITS chunk, the outputs are gathered and the loss block (:190-207) sees the whole batch;
+    autograd sums the replicas' parameter gradients.  The module's BatchNorm buffers after the step are replica 0's
+    (the replicas on the other devices update copies that are dropped).  ``masks``: optional list (one dict per
+    replica) of ReLU masks, as in ``train_step``.  Mutates ``p`` and ``adam_state``; returns (scalars, gradients,
+    per-replica new BatchNorm statistics)."""
+    target, weight = stage_constants(stage, kd)
+    names = trainable_names(p)
+    leaf = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
+    b = x.shape[0]
+    assert b % world == 0
+    per = b // world
+    outs, stats = [], []
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        st = {}
+        outs.append(forward(leaf, cfg, x[sl], y[sl], eps[sl], True, st, masks[r] if masks is not None else None))
+        stats.append({k: v.detach() for k, v in st.items()})
+    out = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    L = losses(out, x, epoch, target, weight)
+    L["loss"].backward()
+    grads = {k: leaf[k].grad.detach() for k in names if leaf[k].grad is not None}
+    total, clipped = clip_grad_norm(grads, grad_clip)
+    adam_step(p, clipped, adam_state, lr)
+    for k, v in stats[0].items():
+        p[k] = v
+    info = {k: float(v.detach()) for k, v in L.items()}
+    info["grad_norm"] = float(total)
+    return info, grads, stats
+
+
 # --------------------------------------------------------------------------------------------
 # purification
 # --------------------------------------------------------------------------------------------
@@ -366,3 +400,20 @@ def purify(p, cfg, data_u8, labels, eps_fn, stage: int, batch: int = 128):
             out_u8[lo + k] = quantize_u8(img[k])
             noise[lo + k] = pert[k].numpy()
     return out_u8, noise
+
+
+# --------------------------------------------------------------------------------------------
+# unlearnable-example ingress
+# --------------------------------------------------------------------------------------------
+def poison_u8(data_u8: np.ndarray, perturbation: torch.Tensor, targets=None, poison_samples_idx=None) -> np.ndarray:
+    """PoisonCIFAR10.__init__ (dataset.py:1235, :1241, :1287-1289) for full-image noise: the perturbation tensor is
+    scaled by 255, clamped to [-255, 255] and permuted to HWC; each selected image becomes
+    uint8(clip(float32(image) + noise, 0, 255)).  ``targets`` given = class-wise (row = label), else sample-wise."""
+    pt = perturbation.to(torch.float32).mul(255).clamp_(-255, 255).permute(0, 2, 3, 1).numpy()
+    out = data_u8.astype(np.float32)
+    idx = range(len(out)) if poison_samples_idx is None else poison_samples_idx
+    for i in idx:
+        noise = pt[int(targets[i])] if targets is not None else pt[i]
+        out[i] = out[i] + noise
+        out[i] = np.clip(out[i], a_min=0, a_max=255)
+    return out.astype(np.uint8)

@@ -245,6 +245,90 @@ def gen_purify(ref):
     print("g4_purify.npz", len(out), "arrays")
 
 
+def gen_purify64(ref):
+    """The same loop at 64x64 (Tiny-ImageNet shape: 200 classes, plain class embedding, stem_end_block 7) over N=12
+    images in batches of 5 (ragged tail)."""
+    out = {}
+    cfg = O.DVAEConfig(image_size=64, spatial_emb=False, num_classes=200)
+    N, B = 12, 5
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, size=(N, 64, 64, 3), dtype=np.uint8)
+    labels = (np.arange(N) * 37) % 200
+    g = torch.Generator().manual_seed(199)
+    eps_all = torch.randn(2, N, cfg.latent_dim, 32, 32, generator=g)
+    out["data"] = data
+    out["labels"] = labels
+    for stage in (0, 1):
+        net, _ = build_ref_model(ref, cfg)
+        net.eval()
+        res = np.empty_like(data)
+        noise = np.zeros((N, 3, 64, 64))
+        idx = 0
+        for lo in range(0, N, B):
+            hi = min(N, lo + B)
+            images = torch.from_numpy(data[lo:hi]).permute(0, 3, 1, 2).float().div(255)   # ToTensor
+            lab = torch.as_tensor(labels[lo:hi], dtype=torch.long)
+            with torch.no_grad():
+                _, rec, mu, lv, z, perturbation = ref_forward(net, images, lab, eps_all[0, lo:hi])
+                images = (images - perturbation).clamp(0, 1).detach()
+                if stage > 0:
+                    _, rec, mu, lv, z, perturbation = ref_forward(net, images, lab, eps_all[1, lo:hi])
+                    images = rec.clamp(0, 1).detach()
+            for k in range(images.shape[0]):
+                res[idx] = np.clip(255 * images[k].cpu().permute(1, 2, 0).numpy(), a_min=0, a_max=255).astype(np.uint8)
+                noise[idx] = perturbation[k].detach().cpu().numpy()
+                idx += 1
+        out[f"stage{stage}.u8"] = res
+        out[f"stage{stage}.noise"] = noise.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g4_purify64.npz"), **out)
+    print("g4_purify64.npz", len(out), "arrays")
+
+
+def gen_dp_step(ref):
+    """One train step the way torch.nn.DataParallel over 2 devices runs it (main_vae_disentangle.py:426-428): the
+    8-image batch goes through the reference module in two contiguous chunks of 4 (train-mode BatchNorm sees one chunk
+    at a time), the outputs are concatenated, the loss block of :190-207 sees all 8 and autograd sums both chunks'
+    parameter gradients.  nn.DataParallel itself needs two GPUs; this is its arithmetic on the reference's own
+    module.  The second chunk runs through a second instance of the reference module whose Parameter objects ARE the
+    first one's (what DataParallel's replicas amount to) and whose BatchNorm buffers are its own and dropped
+    afterwards: the module keeps the first chunk's BatchNorm update, because replica 0 shares the module's buffers."""
+    out = {}
+    cfg = O.DVAEConfig()
+    x, y, eps = O.make_inputs(cfg, 8, seed=4321)
+    net, _ = build_ref_model(ref, cfg)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=0.0)
+    net.zero_grad()
+    net2, _ = build_ref_model(ref, cfg)
+    net2.train()
+    for m1, m2 in zip(net.modules(), net2.modules()):
+        for name in m1._parameters:
+            m2._parameters[name] = m1._parameters[name]
+    parts = [ref_forward(n_, x[4 * r:4 * r + 4], y[4 * r:4 * r + 4], eps[4 * r:4 * r + 4]) for r, n_ in enumerate((net, net2))]
+    stem_out, rec, mu, log_var, z, perturbation = (torch.cat([a[i] for a in parts], 0) for i in range(6))
+    loss_rec = F.mse_loss(rec, x)
+    loss_rec_p = F.mse_loss((rec + perturbation).clamp(0, 1), x)
+    loss_p = F.mse_loss(perturbation, torch.zeros_like(perturbation))
+    kld_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=(0, 1, 2))
+    loss = loss_rec + loss_rec_p + 0.01 * max(kld_loss, 3.0) + max(loss_p, 0.002)       # stage 1, epoch 11
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+    grad_norm = torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)
+    opt.step()
+    for k, v in (("loss", loss), ("loss_rec", loss_rec), ("loss_rec_p", loss_rec_p), ("loss_p", loss_p), ("kld", kld_loss)):
+        out[k] = np.float64(v.item())
+    out["grad_norm"] = np.float64(float(grad_norm))
+    for k, g_ in grads.items():
+        out["gnorm." + k] = np.float64(g_.double().norm())
+    sd = net.state_dict()
+    for k in O.param_shapes(cfg):
+        out["pl2." + k] = np.float64(sd[k].double().norm())
+    for k in ("bn1.running_mean", "layer1.0.bn2.running_var", "layer2.0.shortcut.1.running_mean"):
+        out["stat." + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g6_dp_step.npz"), **out)
+    print("g6_dp_step.npz", len(out), "arrays")
+
+
 def gen_quant_kat():
     """Known answers of np.clip(255*x,0,255).astype(uint8) at the fp32 neighbours of k/255."""
     xs = []
@@ -272,13 +356,22 @@ def gen_state_dict_keys(ref):
     print("state_dict_keys.json", {k: len(v) for k, v in out.items()})
 
 
+def gen_resnet18_keys(ref):
+    """Names and shapes of the CIFAR ResNet18 classifier's state_dict (resnet.py:62-122), the layout of the
+    ``model_state_dict`` entry of the classifier checkpoints (util.py:85-99)."""
+    import json
+    net = ref.ResNet18(num_classes=10)
+    with open(os.path.join(HERE, "resnet18_state_dict_keys.json"), "w") as f:
+        json.dump([[k, list(v.shape)] for k, v in net.state_dict().items()], f)
+    print("resnet18_state_dict_keys.json", len(net.state_dict()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = load_reference()
-    gen_forward(ref)
-    gen_loss_grads(ref)
-    gen_trajectory(ref)
-    gen_purify(ref)
-    gen_quant_kat()
-    gen_state_dict_keys(ref)
+    gens = {"forward": gen_forward, "loss_grads": gen_loss_grads, "trajectory": gen_trajectory, "purify": gen_purify,
+            "purify64": gen_purify64, "dp_step": gen_dp_step, "quant_kat": lambda r: gen_quant_kat(),
+            "state_dict_keys": gen_state_dict_keys, "resnet18_keys": gen_resnet18_keys}
+    for name in (sys.argv[1:] or list(gens)):       # no arguments: regenerate everything
+        gens[name](ref)

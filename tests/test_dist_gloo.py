@@ -42,6 +42,28 @@ def _worker(rank, world, port, n, tmp):
         D.allreduce_sum_(g_local)
         g_ref = (xg.reshape(xg.shape[0], -1) @ w).sum()
         assert torch.allclose(g_local, g_ref * torch.ones(4), rtol=1e-5)
+    # perturbations go to rank 0 only; BatchNorm statistics come from rank 0
+    only0 = D.gather_shards(local_noise, n, dst=0)
+    assert (only0 is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(only0, full.float().mean(dim=(1, 2, 3)))
+    stats = torch.full((6,), float(rank + 1))
+    D.broadcast_(stats, 0)
+    assert torch.equal(stats, torch.ones(6))
+    # classifier stage: per-rank gradients are averaged through one flat bucket
+    from dvae_amd.classifier import DataParallelSGD
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    xs = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    ys = torch.arange(8) % 3
+    per = 8 // world
+    torch.nn.functional.cross_entropy(net(xs[rank * per:(rank + 1) * per]), ys[rank * per:(rank + 1) * per]).backward()
+    DataParallelSGD().sync(net)
+    got_g = [q.grad.clone() for q in net.parameters()]
+    net.zero_grad()
+    torch.nn.functional.cross_entropy(net(xs), ys).backward()
+    for a, q in zip(got_g, net.parameters()):
+        assert torch.allclose(a, q.grad, atol=1e-6)
     sums = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
     D.allreduce_sum_(sums)
     assert torch.equal(sums, torch.tensor([1.0, 2.0, 3.0, 4.0]) * sum(range(1, world + 1)))

@@ -214,6 +214,27 @@ def test_purification_vs_golden(golden_dir, stage):
     assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
 
 
+@pytest.mark.parametrize("stage", [0, 1])
+def test_purification_64x64_vs_golden(golden_dir, stage):
+    """Tiny-ImageNet shape (64x64, 200 classes, plain class embedding, stem_end_block 7): purify_batch against the
+    fixture made with the reference's module, N = 12 in ragged batches of 5.  Same bar as at 32x32."""
+    g = np.load(os.path.join(golden_dir, "g4_purify64.npz"))
+    ocfg, eng, p = make_engine(dict(image_size=64, spatial_emb=False, num_classes=200), 5)
+    data, labels = g["data"], g["labels"]
+    N = data.shape[0]
+    eps_all = torch.randn(2, N, 256, 32, 32, generator=torch.Generator().manual_seed(199))
+    d_dev = torch.from_numpy(data).cuda()
+    out = torch.zeros_like(d_dev)
+    noise = torch.zeros(N, 3, 64, 64, device="cuda")
+    lab = torch.from_numpy(labels).cuda().long()
+    for lo in range(0, N, 5):
+        b = min(5, N - lo)
+        eng.purify_batch(d_dev, out, noise, lab, lo, b, stage, eps_nchw=(eps_all[0, lo:lo + b].cuda(), eps_all[1, lo:lo + b].cuda()))
+    assert rel_err(noise.cpu(), g[f"stage{stage}.noise"]) < 1e-4
+    diff = np.abs(out.cpu().numpy().astype(np.int32) - g[f"stage{stage}.u8"].astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
+
+
 def test_in_kernel_philox_equals_materialised_noise():
     """forward() with a PhiloxEps draws exactly the numbers dvae_philox_normal writes for the same key."""
     ocfg, eng, p = make_engine({}, 4)

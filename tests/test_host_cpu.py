@@ -162,3 +162,92 @@ def test_kernels_do_not_spill_registers(tmp_path):
     assert len(kernels) > 40
     bad = [(n, int(p), int(v)) for n, p, v in kernels if int(p) or int(v)]
     assert not bad, bad
+
+
+def test_yaml_config_stand_in_reads_the_reference_format(tmp_path):
+    """The format of configs/cifar10/resnet18DVAE.yaml / resnet18.yaml: attribute access, named factories, $key substitution,
+    None for absent keys."""
+    from dvae_amd import config as CFG
+    (tmp_path / "resnet18DVAE.yaml").write_text(
+        "num_classes: 10\nepochs: 60\ngrad_clip: 5.0\n# grad_clip: 1.0\nlog_frequency: 100\n\n"
+        "model:\n  name: ResNet18DVAE\n  num_classes: 10\n  stem_end_block: 7\n  latent_dim: 256\n\n"
+        "criterion:\n  name: CrossEntropyLoss\n\n"
+        "optimizer:\n  # name: SGD\n  name: Adam\n  lr: 0.005\n  weight_decay: 0.0\n\n"
+        "scheduler:\n  name: CosineAnnealingLR\n  T_max: $epochs\n  eta_min: 0.0\n\n"
+        "dataset:\n  name: DatasetGenerator\n  train_batch_size: 128\n  eval_batch_size: 128\n")
+    c = CFG.load(str(tmp_path / "resnet18DVAE.yaml")).set_immutable()
+    assert c.epochs == 60 and c.grad_clip == 5.0 and c.log_frequency == 100 and c.absent_key is None
+    m = c.model()
+    assert isinstance(m, dvae_amd.ResNetDVAE) and m.latent_dim == 256 and m.stem_end_block == 7
+    opt = c.optimizer(m.parameters())
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == 0.005
+    sch = c.scheduler(opt)
+    assert isinstance(sch, torch.optim.lr_scheduler.CosineAnnealingLR) and sch.T_max == 60
+    assert isinstance(c.criterion(), torch.nn.CrossEntropyLoss)
+    assert dict(c) == CFG.CIFAR10_DVAE
+    r = CFG.from_dict(CFG.CIFAR10_RESNET18)
+    o = r.optimizer(r.model().parameters())
+    assert isinstance(o, torch.optim.SGD) and o.param_groups[0]["momentum"] == 0.9 and o.param_groups[0]["weight_decay"] == 5e-4
+    with pytest.raises(KeyError):
+        CFG.from_dict({"model": {"name": "DenseNet121"}}).model()
+
+
+def test_classifier_layout_checkpoint_and_evaluator_on_cpu(golden_dir, tmp_path):
+    from dvae_amd.classifier import Evaluator, ResNet18, accuracy, load_model, save_model
+    ref = json.load(open(os.path.join(golden_dir, "resnet18_state_dict_keys.json")))
+    torch.manual_seed(0)
+    m = ResNet18(10)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref
+    out = torch.tensor([[0.1, 0.9, 0.0, 0.0, 0.0, 0.0], [0.8, 0.1, 0.05, 0.0, 0.0, 0.05], [0.0, 0.0, 0.0, 0.0, 0.1, 0.9]])
+    a1, a5 = accuracy(out, torch.tensor([1, 2, 3]), topk=(1, 5))
+    assert abs(float(a1) - 1 / 3) < 1e-6 and abs(float(a5) - 3 / 3) < 1e-6
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=60)
+    save_model(str(tmp_path / "resnet18"), 4, m, opt, sch, ENV={"global_step": 17, "eval_history": [1.0]})
+    st = torch.load(tmp_path / "resnet18.pth", weights_only=True)
+    assert list(st) == ["epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "ENV"] and st["epoch"] == 5
+    m2 = ResNet18(10)
+    ck = load_model(str(tmp_path / "resnet18"), m2, None, None)
+    assert ck["ENV"]["global_step"] == 17
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+
+    class C:
+        num_classes = 10
+        log_frequency = None
+    ds = DD.synthetic_separable(n=96, seed=1)
+    loaders = DD.DatasetGenerator(ds, ds, 32, 40, device="cpu").getDataLoader()
+    ev = Evaluator(loaders, None, C())
+    ev.eval(0, m)
+    assert ev.confusion_matrix.sum() == 96 and ev.acc_meters.count == 96
+    assert abs(float(ev.confusion_matrix.diag().sum()) / 96 - ev.acc_meters.avg) < 1e-6
+
+
+def test_oracle_poison_arithmetic_known_answers():
+    """uint8(clip(float32(x) + clamp(255 p, -255, 255), 0, 255)): truncation toward zero, saturation at both ends."""
+    from oracle import dvae_oracle as O
+    x = np.zeros((1, 32, 32, 3), dtype=np.uint8)
+    x[0, 0, :8, 0] = [0, 10, 10, 10, 250, 255, 100, 100]
+    p = torch.zeros(1, 3, 32, 32)
+    p[0, 0, 0, :8] = torch.tensor([-1 / 255, 2.6 / 255, -2.6 / 255, 8 / 255, 8 / 255, 2.0, -2.0, 0.999 / 255])
+    q = O.poison_u8(x, p)
+    assert q[0, 0, :8, 0].tolist() == [0, 12, 7, 18, 255, 255, 0, 100]
+    assert np.array_equal(q[0, 1:], x[0, 1:])
+    pc = torch.zeros(10, 3, 32, 32)
+    pc[3] = 4 / 255
+    q2 = O.poison_u8(np.full((2, 32, 32, 3), 7, dtype=np.uint8), pc, targets=[3, 4])
+    assert (q2[0] == 11).all() and (q2[1] == 7).all()
+
+
+def test_synthetic_separable_set_is_deterministic_and_shares_templates():
+    a = DD.synthetic_separable(n=40, seed=1)
+    b = DD.synthetic_separable(n=40, seed=1)
+    c = DD.synthetic_separable(n=40, seed=2)
+    assert np.array_equal(a.data, b.data) and not np.array_equal(a.data, c.data)
+    # same class templates under different sample seeds: class means of the two sets correlate strongly
+    ma = np.stack([a.data[a.targets == k].mean(0) for k in range(10)]).reshape(10, -1)
+    mc = np.stack([c.data[c.targets == k].mean(0) for k in range(10)]).reshape(10, -1)
+    cc = np.corrcoef(ma, mc)[:10, 10:]
+    assert (cc.argmax(1) == np.arange(10)).all()
+    p = DD.synthetic_classwise_poison(10, 32, 8 / 255, seed=0)
+    assert tuple(p.shape) == (10, 3, 32, 32) and abs(float(p.abs().max()) - 8 / 255) < 1e-7

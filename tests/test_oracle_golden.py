@@ -130,3 +130,45 @@ def test_quantizer_known_answers(golden_dir):
     x = torch.from_numpy(g["x"]).reshape(1, 1, -1).repeat(3, 1, 1)  # CHW with H=1
     q = O.quantize_u8(x)
     assert np.array_equal(q[0, :, 0], g["q"])
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_purification_64x64_matches_reference(golden_dir, stage):
+    """Tiny-ImageNet shape (64x64, 200 classes, plain class embedding), N = 12 in ragged batches of 5."""
+    g = np.load(os.path.join(golden_dir, "g4_purify64.npz"))
+    cfg = O.DVAEConfig(image_size=64, spatial_emb=False, num_classes=200)
+    p = O.recipe_params(cfg)
+    data, labels = g["data"], g["labels"]
+    N = data.shape[0]
+    eps_all = torch.randn(2, N, cfg.latent_dim, 32, 32, generator=torch.Generator().manual_seed(199))
+    u8, noise = O.purify(p, cfg, data, labels, lambda ps, lo, hi: eps_all[ps, lo:hi], stage, batch=5)
+    close(noise, g[f"stage{stage}.noise"], 5e-5)
+    diff = np.abs(u8.astype(np.int32) - g[f"stage{stage}.u8"].astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
+
+
+def test_data_parallel_step_matches_reference(golden_dir):
+    """DataParallel arithmetic (per-replica BatchNorm statistics, whole-batch loss, summed gradients, replica 0's
+    running statistics kept) against the fixture made from two parameter-sharing instances of the reference module."""
+    g = np.load(os.path.join(golden_dir, "g6_dp_step.npz"))
+    cfg = O.DVAEConfig()
+    p = O.recipe_params(cfg)
+    x, y, eps = O.make_inputs(cfg, 8, seed=4321)
+    info, grads, stats = O.train_step_data_parallel(p, cfg, x, y, eps, {}, 11, 1, world=2)
+    for k in ("loss", "loss_rec", "loss_rec_p", "loss_p", "kld", "grad_norm"):
+        close(info[k], g[k], 1e-4)
+    for k, v in grads.items():
+        ref = float(g["gnorm." + k])
+        assert abs(float(v.double().norm()) - ref) <= 1e-4 * max(ref, 1e-6) + 1e-9, k
+    for k in O.param_shapes(cfg):
+        if k in NULL_GRAD_BIASES:
+            continue
+        ref = float(g["pl2." + k])
+        assert abs(float(p[k].double().norm()) - ref) <= 2e-4 * max(ref, 1e-6), k
+    for k in ("bn1.running_mean", "layer1.0.bn2.running_var", "layer2.0.shortcut.1.running_mean"):
+        close(p[k].numpy(), g["stat." + k])
+        assert not np.allclose(stats[0][k].numpy(), stats[1][k].numpy())      # the replicas saw different chunks
+    # the whole-batch step is a different function: BatchNorm over 8 images is not BatchNorm over 4 + 4
+    p1 = O.recipe_params(cfg)
+    info1, _, _ = O.train_step(p1, cfg, x, y, eps, {}, 11, 1)
+    assert abs(info1["loss"] - info["loss"]) > 1e-6
