@@ -58,7 +58,23 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the train step from captured HIP graphs (default: launch by launch; "
                     "the step is GPU-bound and the two-stream schedule runs faster outside a graph)")
     ap.add_argument("--no-purify", action="store_true", help="profiling aid: skip the purification region")
+    ap.add_argument("--no-f32", action="store_true", help="skip the fp32 (reference precision) leg of a bf16 run")
+    ap.add_argument("--no-pass", action="store_true", help="skip the whole-dataset pass through purify_dataset")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(n):
+    """``python bench.py --gpus N`` outside torchrun: start N ranks as a child job before anything touches the GPU and
+    leave with its exit code (replacing this process is not an option once a GPU runtime is loaded)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def barrier(world):
@@ -98,8 +114,107 @@ def cpu_baseline(n_images, stage=1, S=32):
             "sample": f"{n_images} synthetic {S}x{S}x3 images, stage-1 purification (2 forwards), batch 128, fp32 torch CPU"}
 
 
+def cpu_baseline_train(steps=5, batch=128):
+    """The CPU oracle's D-VAE train step (forward, losses, backward, clip, Adam; no model_c monitors) at the reference
+    batch size."""
+    from oracle import dvae_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.DVAEConfig()
+    p = O.recipe_params(cfg)
+    x, y, eps = O.make_inputs(cfg, batch, seed=0)
+    st = {}
+    O.train_step(p, cfg, x, y, eps, st, 11, 1)              # warm-up
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        O.train_step(p, cfg, x, y, eps, st, 11, 1)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": batch / med, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train steps at batch {batch} (median), synthetic 32x32x3, fp32 torch CPU, no monitor compute"}
+
+
+def purify_region(eng, a, world, data, out, noise, labels, Bp, steps, probe_name):
+    """Warm-up, then ``steps`` timed purification batches (barrier + synchronize on both sides, max over ranks).
+    Returns (images/s over all ranks, ms per step, sorted HIP-event times of the probed conv launch in ms)."""
+    nb = data.shape[0] // Bp
+    for i in range(a.warmup):
+        eng.purify_batch(data, out, noise, labels, (i % nb) * Bp, Bp, a.stage)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    eng.probe = None
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.probe = (probe_name, ev[i])
+        eng.purify_batch(data, out, noise, labels, ((a.warmup + i) % nb) * Bp, Bp, a.stage)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    eng.probe = None
+    return world * Bp * steps / dt, dt / steps * 1e3, sorted(s.elapsed_time(e) for s, e in ev)
+
+
+def probe_roofline(dtype_name, probe_ms, Bp, px, S):
+    """Roofline object of the probed launch (layer1.0.conv1: 3x3 conv 64->64).  Algorithmic work per image:
+    2 * 37 748 736 FLOP and (read x + write y) = 2 * 64 ch * 1024 px * element size bytes.  fp32: 144 FLOP/B against a
+    ridge of 157.3 T / 8 T = 20 -> MFMA-bound.  bf16: 288 FLOP/B against a ridge of 2500 / 8 = 312 -> HBM-bound (just)."""
+    avg = sum(probe_ms) / len(probe_ms)
+    peak = PEAK_TFLOPS[dtype_name]
+    tflops = 2.0 * CONV_PROBE_MACS * px * Bp / (avg * 1e-3) / 1e12
+    nbytes = 2.0 * 64 * 1024 * px * (4 if dtype_name == "f32" else 2) * Bp
+    gbs = nbytes / (avg * 1e-3) / 1e9
+    if dtype_name == "bf16":
+        roof = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                "mfma_tflops": tflops, "mfma_frac": tflops / peak}
+        kname = "conv_halo_bf16_kernel<64,64,32>"
+    else:
+        roof = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "hbm_gbs": gbs}
+        kname = "igemm_kernel<float,2,1,2,2>"
+    roof.update(kernel=f"{kname} ({CONV_PROBE}: 3x3 conv 64->64 @{S}x{S}, {Bp} images/launch)", avg_launch_ms=avg,
+                launches_timed=len(probe_ms), algorithmic_bytes_per_launch=nbytes,
+                algorithmic_flops_per_launch=2.0 * CONV_PROBE_MACS * px * Bp,
+                traffic=None)          # HBM bytes are a PMC figure: not measured inside this run
+    tpath = os.path.join(ROOT, "profiles", f"r02_traffic_{dtype_name}.json")
+    if os.path.exists(tpath) and Bp == 1024 and S == 32:
+        roof["traffic_from_profiles"] = {"file": os.path.relpath(tpath, ROOT), "hbm_bytes": json.load(open(tpath)).get("hbm_bytes")}
+    return roof
+
+
+def dataset_pass(a, world, rank, dtype_name, S, cfg):
+    """One stage-1 pass over the whole synthetic set through the drop-in API (``purify_dataset``): upload of this rank's
+    shard, the per-batch kernels, the all-gather of the uint8 shards + gather of the perturbations to rank 0, and the host
+    tail (device -> host copies, float64 conversion, ``dataset.data`` overwritten in place).  Wall time, max over ranks."""
+    from dvae_amd import data as DD
+    from dvae_amd.model import ResNet18DVAE
+    from dvae_amd.trainer import purify_dataset
+    torch.manual_seed(0)
+    m = ResNet18DVAE(num_classes=cfg.num_classes, stem_end_block=7, latent_dim=256, act_dtype=dtype_name)
+    m.sample_wise, m.use_y, m.spatial_emb = True, False, cfg.spatial_emb
+    m.set_spatial_emb()
+    m = m.cuda()
+    ds = DD.synthetic_cifar(n=a.images, size=S, classes=cfg.num_classes, seed=0)
+    small = DD.ArrayDataset(ds.data[:a.purify_batch * world].copy(), ds.targets[:a.purify_batch * world])
+    purify_dataset(m, small, a.stage, batch=a.purify_batch, seed=0)              # warm-up: engine build, first launches
+    tm = {}
+    barrier(world)
+    t0 = time.perf_counter()
+    purify_dataset(m, ds, a.stage, batch=a.purify_batch, seed=0, timings=tm)
+    barrier(world)
+    wall = max_over_ranks(time.perf_counter() - t0, world)
+    out = {"images": a.images, "stage": a.stage, "wall_s": wall, "images_per_sec": a.images / wall}
+    for k, v in tm.items():
+        out[k] = max_over_ranks(v, world)
+    out["kernel_only_images_per_sec"] = a.images / out["kernels_s"]
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(a.gpus))
+    if a.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU "
+                 "(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) or drop WORLD_SIZE")
     # DVAE_BENCH_WATCHDOG=<seconds>: a run that has not finished by then prints every thread's Python stack and exits
     # (a hung collective or a kernel that never returns then names the line it sits on)
     wd = float(os.environ.get("DVAE_BENCH_WATCHDOG", "0"))
@@ -142,23 +257,12 @@ def main():
     noise = torch.empty(n_local, 3, S, S, device="cuda")
     nb = n_local // Bp
 
-    def purify_step(i):
-        eng.purify_batch(data, out, noise, labels, (i % nb) * Bp, Bp, a.stage)
-
     steps_p = 1 if a.no_purify else a.steps
-    for i in range(0 if a.no_purify else a.warmup):
-        purify_step(i)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps_p)]
-    eng.probe = None
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(steps_p):
-        eng.probe = (CONV_PROBE, ev[i]) if i < len(ev) else None
-        purify_step(a.warmup + i)
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    eng.probe = None
-    purify_ips = world * Bp * steps_p / dt
+    if a.no_purify:
+        a_w, a.warmup = a.warmup, 0
+    purify_ips, purify_ms, probe_ms = purify_region(eng, a, world, data, out, noise, labels, Bp, steps_p, CONV_PROBE)
+    if a.no_purify:
+        a.warmup = a_w
     # extra, never `value`: the same pass without the first forward's reconstruction decoder, whose result the
     # reference drops (main_vae_disentangle.py:61-62); outputs are bit-identical (tests/test_gpu_bf16.py)
     lean_ips = None
@@ -169,8 +273,6 @@ def main():
             eng.purify_batch(data, out, noise, labels, (i % nb) * Bp, Bp, 1, skip_unread=True)
         barrier(world)
         lean_ips = world * Bp * steps_p / max_over_ranks(time.perf_counter() - t0, world)
-    probe_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    probe_avg = sum(probe_ms) / len(probe_ms)
 
     # one all-gather of the purified shards (once per pass, outside the per-batch hot loop)
     allgather_ms = None
@@ -196,6 +298,8 @@ def main():
                 h = t.cpu()
                 dist.all_reduce(h)
                 t.copy_(h)
+            if os.environ.get("DVAE_BENCH_GLOO_DEVICE") == "1":          # gloo on the device tensors themselves
+                allreduce = lambda t: dist.all_reduce(t)      # noqa: E731
         else:
             allreduce = None
         idx = torch.randperm(n_local, device="cuda", dtype=torch.int64).to(torch.int32)
@@ -219,36 +323,33 @@ def main():
         train_ips = world * Bt * a.steps / dtt
         train_ms = dtt / a.steps * 1e3
 
+    # ---------------- the reference's own precision, same run -------------------------------------
+    f32_leg = None
+    if a.dtype == "bf16" and not a.no_f32 and not a.no_purify:
+        del eng
+        torch.cuda.empty_cache()
+        eng32 = DVAEEngine(cfg, Bp, "cuda", L.F32, seed=0)
+        init_params(eng32)
+        ips32, ms32, probe32 = purify_region(eng32, a, world, data, out, noise, labels, Bp, max(3, steps_p // 4), CONV_PROBE)
+        r32 = probe_roofline("f32", probe32, Bp, px, S)
+        f32_leg = {"value": ips32, "unit": "images/s", "ms_per_step": ms32, "dtype": "f32",
+                   "probe_frac": r32["frac"], "roofline": r32}
+        del eng32
+        torch.cuda.empty_cache()
+
+    # ---------------- one whole-dataset pass through the drop-in API -------------------------------
+    pass_obj = None
+    if not a.no_pass and not a.no_purify:
+        pass_obj = dataset_pass(a, world, rank, a.dtype, S, cfg)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    peak = PEAK_TFLOPS[a.dtype]
-    probe_tflops = 2.0 * CONV_PROBE_MACS * px * Bp / (probe_avg * 1e-3) / 1e12
-    # Roofline of the dominant kernel, the 3x3 64->64 conv at 32x32.  Algorithmic work per image: 2 * 37 748 736
-    # FLOP and (read x + write y) = 2 * 64 ch * 1024 px * element size bytes.  fp32: 144 FLOP/B against a ridge of
-    # 157.3 T / 8 T = 20 -> MFMA-bound.  bf16: 288 FLOP/B against a ridge of 2500 / 8 = 312 -> HBM-bound (just).
-    esz = 4 if a.dtype == "f32" else 2
-    probe_bytes = 2.0 * 64 * 1024 * px * esz * Bp
-    probe_gbs = probe_bytes / (probe_avg * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{a.dtype}.json")
-    if os.path.exists(tpath) and Bp == 1024 and S == 32:
-        traffic = json.load(open(tpath)).get("hbm_bytes")     # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch
-    kname = "conv_halo_bf16_kernel<64,64,32>" if a.dtype == "bf16" else "igemm_kernel<float,2,1,2,2>"
-    if a.dtype == "bf16":
-        roof = {"bound": "hbm", "achieved": probe_gbs, "peak": 8000.0, "unit": "GB/s", "frac": probe_gbs / 8000.0,
-                "mfma_tflops": probe_tflops, "mfma_frac": probe_tflops / peak}
-    else:
-        roof = {"bound": "mfma", "achieved": probe_tflops, "peak": peak, "unit": "TFLOP/s", "frac": probe_tflops / peak,
-                "hbm_gbs": probe_gbs}
-    roof.update(kernel=f"{kname} ({CONV_PROBE}: 3x3 conv 64->64 @{S}x{S}, {Bp} images/launch)", avg_launch_ms=probe_avg,
-                launches_timed=len(probe_ms), algorithmic_bytes_per_launch=probe_bytes,
-                algorithmic_flops_per_launch=2.0 * CONV_PROBE_MACS * px * Bp, traffic=traffic)
     res = {
         "metric": "purified images/sec (node) + VAE train imgs/sec, " + ("CIFAR-10 shape" if S == 32 else f"{S}x{S} Tiny-ImageNet shape"),
         "value": purify_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / steps_p * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": purify_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": f"synthetic uint8 {S}x{S}x3 images resident in HBM, random-init weights",
         "config": {"workload": ("CIFAR-10 shape 32x32x3" if S == 32 else f"Tiny-ImageNet shape {S}x{S}x3, 200 classes") +
                                ", ResNet18DVAE(seb=7, latent=256), " +
@@ -260,10 +361,16 @@ def main():
         "purify_images_per_sec_skipping_unread_decoder": lean_ips,
         "purify_tflops": 2.0 * (1 + a.stage) * FWD_MACS * px * purify_ips / 1e12,
         "train_tflops": (2.0 * TRAIN_MACS * px * train_ips / 1e12) if train_ips else None,
-        "roofline": roof,
+        "roofline": probe_roofline(a.dtype, probe_ms, Bp, px, S),
     }
+    if f32_leg is not None:
+        res["f32"] = f32_leg
+    if pass_obj is not None:
+        res["pass"] = pass_obj
     if not a.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(1024 // px, S=S)
+        if S == 32:
+            res["cpu_baseline_train"] = cpu_baseline_train()
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -367,7 +367,7 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
     on each purified set (same initialisation, same batch order) must reach a clean test accuracy within +-1 % of the
     oracle-purified run's."""
     torch.manual_seed(0)
-    N, NT = 1536, 4096
+    N, NT = 4096, 4096
     clean = DD.synthetic_separable(n=N, seed=21)
     test = DD.synthetic_separable(n=NT, seed=22)
     ds = DD.ArrayDataset(clean.data.copy(), clean.targets.copy())
@@ -379,7 +379,7 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
     m.train()
     opt = FusedAdam(m, lr=5e-3)
     tr = VAE_Trainer(loaders, None, Cfg(), stage=1, kd=3.0)
-    for epoch in range(10):
+    for epoch in range(30):                  # 960 steps: enough for reconstructions that keep the class templates
         for images, labels in loaders["train_dataset"]:
             tr.train_batch(images, labels, m, None, opt, epoch)
             tr.global_step += 1
@@ -403,7 +403,7 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
     dq = np.abs(purified["f32"].astype(int) - purified["oracle"].astype(int))
     assert dq.max() <= 1 and (dq != 0).mean() <= 0.005
     accs = {}
-    cfg = dvae_amd.config.from_dict(dict(dvae_amd.config.CIFAR10_RESNET18, epochs=6, log_frequency=1000))
+    cfg = dvae_amd.config.from_dict(dict(dvae_amd.config.CIFAR10_RESNET18, epochs=8, log_frequency=1000))
     for tag, arr in purified.items():
         torch.manual_seed(1)
         tds = DD.ArrayDataset(arr.copy(), ds.targets.copy(), transform="crop_flip")
@@ -417,5 +417,5 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
         train(1, model, None, None, optimizer, scheduler, cfg.criterion(), trainer, Evaluator(ld, None, cfg), ENV, ld, cfg)
         accs[tag] = ENV["eval_history"][-1]
     print("clean test accuracy after training on purified data:", accs)
-    assert accs["oracle"] > 50.0, accs
+    assert accs["oracle"] > 90.0, accs
     assert abs(accs["f32"] - accs["oracle"]) <= 1.0 and abs(accs["bf16"] - accs["oracle"]) <= 1.0, accs
