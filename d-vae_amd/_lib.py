@@ -53,6 +53,7 @@ _SIGS = {
     "dvae_wgrad_reduce_batch": (C.c_int, [_P, _I, _I, _P]),
     "dvae_norm_workspace_bytes": (_Z, [_I, _I, _I]),
     "dvae_norm_fwd_train": (C.c_int, [_P] * 9 + [_P, _Z, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "dvae_norm_fwd_train_static": (C.c_int, [_P] * 9 + [_I, _I, _I, _I, _F, _F, _I, _P]),
     "dvae_bn_fwd_eval": (C.c_int, [_P] * 8 + [_I, _I, _I, _F, _I, _P]),
     "dvae_bn_fold_eval": (C.c_int, [_P] * 6 + [_I, _F, _P]),
     "dvae_norm_bwd": (C.c_int, [_P] * 10 + [_P, _Z, _I, _I, _I, _I, _I, _P]),

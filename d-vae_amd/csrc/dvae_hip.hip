@@ -15,6 +15,33 @@ thread_local char g_err[512] = "";
 }
 using namespace dvae;
 
+// Library-owned scratch of dvae_norm_fwd_train_static (see there).  `scratch` names the array in host code only as a
+// symbol: its device address is looked up per device, once, and kept in g_scratch_ptr.
+static __device__ __align__(256) float scratch[DVAE_STATIC_SCRATCH_FLOATS];
+static float* g_scratch_ptr[64];
+static std::atomic<unsigned long long> g_scratch_known{0ull};
+
+static float* static_scratch_for_current_device() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        snprintf(g_err, sizeof(g_err), "static scratch: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return nullptr;
+    }
+    const unsigned long long bit = 1ull << dev;
+    if (!(g_scratch_known.load(std::memory_order_acquire) & bit)) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));      // address of this device's copy of the array
+        if (e != hipSuccess || !p) {
+            snprintf(g_err, sizeof(g_err), "static scratch: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = p;                   // two threads racing here store the same address
+        g_scratch_known.fetch_or(bit, std::memory_order_release);
+    }
+    return g_scratch_ptr[dev];
+}
+
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
     long g = (n + block - 1) / block;
@@ -325,10 +352,10 @@ static int norm_check(int groups, int rows_per_group, int C, int dtype) {
     return DVAE_OK;
 }
 
-int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* gamma, const float* beta,
-                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* ws,
-                        size_t ws_bytes, int groups, int rows_per_group, int C, int relu, float momentum, float eps,
-                        int dtype, void* st) {
+static int norm_fwd_train_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* ws,
+                               size_t ws_bytes, int groups, int rows_per_group, int C, int relu, float momentum, float eps,
+                               int dtype, void* st) {
     int rc = norm_check(groups, rows_per_group, C, dtype);
     if (rc) return rc;
     const NormGeom g = norm_geom(groups, rows_per_group, C);
@@ -362,6 +389,35 @@ int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* ga
                                   (const T*)x, (const T*)res, (T*)y, scale_shift, rows_per_group, C, nvec, relu);)
     DVAE_CHECK_LAUNCH("norm_apply");
     return DVAE_OK;
+}
+
+int dvae_norm_fwd_train(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* ws,
+                        size_t ws_bytes, int groups, int rows_per_group, int C, int relu, float momentum, float eps,
+                        int dtype, void* st) {
+    return norm_fwd_train_impl(x, res, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, ws_bytes, groups,
+                               rows_per_group, C, relu, momentum, eps, dtype, st);
+}
+
+// The same normalisation for callers that cannot allocate: the partial statistics and the scale / shift pairs go to
+// `scratch`, a fixed array in this library's device image (every GPU the library runs on holds its own copy until the
+// process ends).  Host code must not pass the array's name to a kernel: the name is a host-side stand-in, and the
+// array's address on the current device is what hipGetSymbolAddress returns, looked up once per device.
+int dvae_norm_fwd_train_static(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd, int groups,
+                               int rows_per_group, int C, int relu, float momentum, float eps, int dtype, void* st) {
+    int rc = norm_check(groups, rows_per_group, C, dtype);
+    if (rc) return rc;
+    const size_t need = norm_ws_floats(norm_geom(groups, rows_per_group, C));
+    if (need > DVAE_STATIC_SCRATCH_FLOATS)
+        DVAE_FAIL(DVAE_EWORKSPACE, "norm_fwd_train_static: %d group(s) of %d rows x %d channels need %zu scratch floats, "
+                  "the library-owned scratch holds %d (use dvae_norm_fwd_train with a workspace of your own)",
+                  groups, rows_per_group, C, need, DVAE_STATIC_SCRATCH_FLOATS);
+    float* ptr = static_scratch_for_current_device();
+    if (!ptr) return DVAE_ELAUNCH;                        // g_err says which HIP call failed
+    return norm_fwd_train_impl(x, res, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ptr,
+                               (size_t)DVAE_STATIC_SCRATCH_FLOATS * sizeof(float), groups, rows_per_group, C, relu, momentum,
+                               eps, dtype, st);
 }
 
 int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,

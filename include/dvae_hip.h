@@ -137,6 +137,22 @@ int dvae_norm_fwd_train(const void* x, const void* residual, void* y,
                         void* workspace, size_t workspace_bytes,
                         int groups, int rows_per_group, int C, int relu,
                         float momentum, float eps, int dtype, void* stream);
+/* dvae_norm_fwd_train without a workspace argument, for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same
+ * kernels and bit-identical results; the partial statistics and scale / shift pairs live in a scratch array that is part
+ * of the library's device image (DVAE_STATIC_SCRATCH_FLOATS floats = 1 MiB on every GPU the library is used on, held
+ * until the process ends).  The call allocates and frees nothing.  Shapes that need more scratch than that
+ * (dvae_norm_workspace_bytes(groups, rows_per_group, C) > 1 MiB: BatchNorm with C > 128 at large row counts,
+ * InstanceNorm of more than ~240 images of 32x32x64) return DVAE_EWORKSPACE and run nothing.  Every call on a GPU uses
+ * that GPU's one array: calls that overlap on one GPU (different streams or threads) race; nothing in it needs to start
+ * at zero (each call overwrites every entry it later reads). */
+#define DVAE_STATIC_SCRATCH_FLOATS 262144
+int dvae_norm_fwd_train_static(const void* x, const void* residual, void* y,
+                               const float* gamma, const float* beta,          /* NULL for InstanceNorm */
+                               float* running_mean, float* running_var,        /* NULL for InstanceNorm */
+                               float* save_mean, float* save_invstd,
+                               int groups, int rows_per_group, int C, int relu,
+                               float momentum, float eps, int dtype, void* stream);
 /* statistics only: save_mean / save_invstd and scale_shift [groups][2][C] (scale = gamma * invstd, shift = beta -
  * mean * scale), for a consumer that applies the normalisation itself (dvae_epilogue.in_scale_shift) */
 int dvae_norm_fwd_stats(const void* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
