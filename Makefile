@@ -10,7 +10,7 @@ all: $(LIB)
 
 $(LIB): $(CSRC)/dvae_hip.hip $(HDRS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wall -Wno-unused-function \
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=1000000 \
 	    -o $@ $(CSRC)/dvae_hip.hip
 
 clean:

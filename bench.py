@@ -289,19 +289,10 @@ def main():
     if not a.no_train:
         Bt = a.train_batch
         eng.set_hyper(lr=5e-3, max_norm=5.0, grad_scale=1.0 / world, steps_done=0)
-        if world > 1 and backend == "nccl":
-            allreduce = lambda t: dist.all_reduce(t)      # noqa: E731  RCCL, on the card, ordered with the current stream
-        elif world > 1:
-            # rehearsal: gloo's own staging of device tensors stalls now and then when two ranks share one card; stage
-            # through the host here so that the run exercises the multi-rank logic and nothing else
-            def allreduce(t):
-                h = t.cpu()
-                dist.all_reduce(h)
-                t.copy_(h)
-            if os.environ.get("DVAE_BENCH_GLOO_DEVICE") == "1":          # gloo on the device tensors themselves
-                allreduce = lambda t: dist.all_reduce(t)      # noqa: E731
-        else:
-            allreduce = None
+        # RCCL reduces the device tensors in place, ordered with the current stream; the gloo rehearsal goes through a
+        # host copy (dvae_amd.dist: gloo stalls on device tensors of a process with queued kernels when ranks share a card)
+        from dvae_amd import dist as DD_
+        allreduce = DD_.allreduce_sum_ if world > 1 else None
         idx = torch.randperm(n_local, device="cuda", dtype=torch.int64).to(torch.int32)
 
         def train_step(i):

@@ -32,6 +32,7 @@ class Epilogue(C.Structure):
 _P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 _SIGS = {
     "dvae_act_channels": (C.c_int, [_I]),
+    "dvae_set_option": (C.c_int, [C.c_char_p, _I]),
     "dvae_u8_to_act": (C.c_int, [_P, _P, _L, _P, _I, _I, _I, _P]),
     "dvae_nchw_to_act": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dvae_act_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -4,6 +4,7 @@
 #include "elementwise.hpp"
 #include "igemm.hpp"
 #include "conv_halo.hpp"
+#include "conv_wreg.hpp"
 #include "conv_image.hpp"
 #include "wgrad_halo.hpp"
 #include "conv_stem.hpp"
@@ -42,6 +43,9 @@ static float* static_scratch_for_current_device() {
     return g_scratch_ptr[dev];
 }
 
+// diagnostic switches (dvae_set_option): which of two equivalent kernels serves a launch
+static std::atomic<int> g_opt_wreg{1};
+
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
     long g = (n + block - 1) / block;
@@ -62,7 +66,13 @@ static inline int act_c(int C, int dtype) {
 
 extern "C" {
 
-const char* dvae_version(void) { return "dvae_hip 0.1 (gfx950)"; }
+const char* dvae_version(void) { return "dvae_hip 0.2 (gfx950)"; }
+
+int dvae_set_option(const char* name, int value) {
+    if (!name) DVAE_FAIL(DVAE_EINVAL, "set_option: null name");
+    if (!strcmp(name, "conv_wreg")) { g_opt_wreg.store(value != 0); return DVAE_OK; }
+    DVAE_FAIL(DVAE_EINVAL, "set_option: unknown option '%s'", name);
+}
 const char* dvae_last_error(void) { return g_err; }
 int dvae_act_channels(int C) { return act_channels(C); }
 
@@ -158,6 +168,11 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
                                "(see dvae_conv_supports_input_norm)");
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
+    if (g_opt_wreg.load() && !e.in_scale_shift && !e.out_stats &&
+        try_launch_wreg_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_wreg");
+        return DVAE_OK;
+    }
     if (try_launch_halo_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), e.in_scale_shift,
                              e.in_relu, nullptr, e.out_stats)) {
         DVAE_CHECK_LAUNCH("conv_halo");
@@ -202,6 +217,10 @@ int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, co
     if (rc) return rc;
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 1, S(st));
+    if (g_opt_wreg.load() && try_launch_wreg_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_wreg");
+        return DVAE_OK;
+    }
     if (try_launch_halo_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
         DVAE_CHECK_LAUNCH("conv_halo");
         return DVAE_OK;

@@ -64,10 +64,23 @@ def epoch_permutation(n: int, epoch: int, seed: int, device="cpu"):
     return torch.randperm(n, generator=g).to(device)
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo moves device tensors through its own staging copies; when the calling process still has kernels queued and
+    another rank shares the card (the CPU-backend rehearsal of the multi-rank paths), that stalls for tens of seconds
+    (profiles/r02_gloo_stall_probe_*.txt).  Device tensors therefore cross gloo through an explicit host copy, which
+    also drains the stream.  RCCL ("nccl") works on the device tensors themselves, ordered with the current stream."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def allreduce_sum_(t: torch.Tensor):
     """In-place sum over ranks (identity on one process)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _host_staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -82,6 +95,11 @@ def all_gather_shards(local: torch.Tensor, n: int) -> torch.Tensor:
     if local.shape[0] < per:
         pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
+    if _host_staged(local):
+        h = local.cpu()
+        out = torch.empty((world * per,) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h.contiguous())
+        return out[:n].to(local.device)
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n]
@@ -100,6 +118,8 @@ def gather_shards(local: torch.Tensor, n: int, dst: int = 0):
         pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
     local = local.contiguous()
+    if _host_staged(local):
+        local = local.cpu()                                 # rank dst then holds the result on the host
     if rank == dst:
         out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.gather(local, list(out.split(per, 0)), dst=dst)
@@ -111,5 +131,10 @@ def gather_shards(local: torch.Tensor, n: int, dst: int = 0):
 def broadcast_(t: torch.Tensor, src: int = 0):
     """In-place broadcast from rank ``src`` (identity on one process)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(t, src)
+        if _host_staged(t):
+            h = t.cpu()
+            dist.broadcast(h, src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src)
     return t

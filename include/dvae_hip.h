@@ -82,6 +82,10 @@ typedef struct dvae_epilogue {
 
 const char* dvae_version(void);
 const char* dvae_last_error(void);
+/* Diagnostic switch, process-wide: "conv_wreg" = 0 routes the 3x3 unit-stride bf16 convolutions to the kernel that keeps
+ * the weights in LDS instead of the one that keeps them in registers (same results to rounding; for A/B timing inside
+ * one process).  No counterpart in the reference. */
+int dvae_set_option(const char* name, int value);
 int dvae_act_channels(int C);
 
 /* ---- layout conversion at the module boundary ------------------------------------------------
