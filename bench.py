@@ -157,26 +157,29 @@ def purify_region(eng, a, world, data, out, noise, labels, Bp, steps, probe_name
 def probe_roofline(dtype_name, probe_ms, Bp, px, S):
     """Roofline object of the probed launch (layer1.0.conv1: 3x3 conv 64->64).  Algorithmic work per image:
     2 * 37 748 736 FLOP and (read x + write y) = 2 * 64 ch * 1024 px * element size bytes.  fp32: 144 FLOP/B against a
-    ridge of 157.3 T / 8 T = 20 -> MFMA-bound.  bf16: 288 FLOP/B against a ridge of 2500 / 8 = 312 -> HBM-bound (just)."""
+    ridge of 157.3 T / 8 T = 20 -> MFMA-bound.  bf16: 288 FLOP/B against a ridge of 2500 / 8 = 312 -> at the ridge."""
     avg = sum(probe_ms) / len(probe_ms)
     peak = PEAK_TFLOPS[dtype_name]
     tflops = 2.0 * CONV_PROBE_MACS * px * Bp / (avg * 1e-3) / 1e12
     nbytes = 2.0 * 64 * 1024 * px * (4 if dtype_name == "f32" else 2) * Bp
     gbs = nbytes / (avg * 1e-3) / 1e9
-    if dtype_name == "bf16":
-        roof = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                "mfma_tflops": tflops, "mfma_frac": tflops / peak}
-        kname = "conv_halo_bf16_kernel<64,64,32>"
-    else:
-        roof = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "hbm_gbs": gbs}
-        kname = "igemm_kernel<float,2,1,2,2>"
+    # (bf16 sits at the ridge -- 30.9 us of MFMA against 33.5 us of HBM per 1024 images at the nominal peaks -- and the
+    # kernel's time goes into the matrix pipe: it is reported against the MFMA peak, the HBM rate beside it)
+    roof = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+            "hbm_gbs": gbs, "hbm_frac": gbs / 8000.0}
+    kname = "conv_wreg_bf16_kernel<64,64,1,false>" if dtype_name == "bf16" else "igemm_kernel<float,2,1,2,2>"
     roof.update(kernel=f"{kname} ({CONV_PROBE}: 3x3 conv 64->64 @{S}x{S}, {Bp} images/launch)", avg_launch_ms=avg,
                 launches_timed=len(probe_ms), algorithmic_bytes_per_launch=nbytes,
                 algorithmic_flops_per_launch=2.0 * CONV_PROBE_MACS * px * Bp,
-                traffic=None)          # HBM bytes are a PMC figure: not measured inside this run
+                traffic=None, traffic_source=None)
+    # HBM bytes per launch are a PMC figure (rocprofv3 --pmc, one counter per pass, of this same command with fewer steps):
+    # not measurable inside this run, so the figure of the committed passes is reported when they are of this launch
     tpath = os.path.join(ROOT, "profiles", f"r02_traffic_{dtype_name}.json")
     if os.path.exists(tpath) and Bp == 1024 and S == 32:
-        roof["traffic_from_profiles"] = {"file": os.path.relpath(tpath, ROOT), "hbm_bytes": json.load(open(tpath)).get("hbm_bytes")}
+        t = json.load(open(tpath))
+        if kname in t.get("kernel", "").replace(", ", ","):
+            roof["traffic"] = t.get("hbm_bytes")
+            roof["traffic_source"] = os.path.relpath(tpath, ROOT) + " (PMC passes of scripts/profile_r02.sh, not this run)"
     return roof
 
 
