@@ -58,9 +58,6 @@ _SIGS = {
     "dvae_bn_fwd_eval": (C.c_int, [_P] * 8 + [_I, _I, _I, _F, _I, _P]),
     "dvae_bn_fold_eval": (C.c_int, [_P] * 6 + [_I, _F, _P]),
     "dvae_norm_bwd": (C.c_int, [_P] * 10 + [_P, _Z, _I, _I, _I, _I, _I, _P]),
-    "dvae_bn_onepass_blocks": (C.c_int, [_L, _I, _I]),
-    "dvae_bn_fwd_train_onepass": (C.c_int, [_P] * 9 + [_P, _Z, _P, _L, _I, _I, _F, _F, _I, _P]),
-    "dvae_bn_bwd_onepass": (C.c_int, [_P] * 10 + [_P, _Z, _P, _L, _I, _I, _I, _P]),
     "dvae_emb_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dvae_emb_add_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dvae_emb_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -10,7 +10,6 @@
 #include "conv_stem.hpp"
 #include "conv_point.hpp"
 #include "norm.hpp"
-#include "norm_onepass.hpp"
 
 namespace dvae {
 thread_local char g_err[512] = "";
@@ -539,53 +538,6 @@ int dvae_norm_bwd(const void* dy, const void* y, const void* x, void* dx, void* 
                                   (const T*)dy, (const T*)y, (const T*)x, (T*)dx, (T*)dres, save_mean, save_invstd,
                                   coef, rows_per_group, C, nvec, relu);)
     DVAE_CHECK_LAUNCH("norm_bwd_apply");
-    return DVAE_OK;
-}
-
-// ---- training BatchNorm in one launch each way (norm_onepass.hpp) ----
-int dvae_bn_onepass_blocks(long rows, int C, int dtype) {
-    if (dtype != DVAE_BF16) return 0;
-    return onepass_plan(rows, C).blocks;
-}
-
-int dvae_bn_fwd_train_onepass(const void* x, const void* res, void* y, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* ws,
-                              size_t ws_bytes, unsigned* barrier, long rows, int C, int relu, float momentum, float eps,
-                              int dtype, void* st) {
-    const OnepassPlan op = dtype == DVAE_BF16 ? onepass_plan(rows, C) : OnepassPlan{0, 0};
-    if (!op.nv) DVAE_FAIL(DVAE_EINVAL, "bn_fwd_train_onepass: %ld rows x %d channels (dtype %d) do not fit one grid "
-                                       "(see dvae_bn_onepass_blocks)", rows, C, dtype);
-    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !ws || !barrier)
-        DVAE_FAIL(DVAE_EINVAL, "bn_fwd_train_onepass: null argument");
-    if (ws_bytes < (size_t)op.blocks * 3 * C * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "bn_fwd_train_onepass: workspace too small");
-    const long nvec = rows * C / 8;
-#define ONEPASS_FWD(NV)                                                                                                \
-    hipLaunchKernelGGL((bn_onepass_fwd_kernel<NV>), dim3(op.blocks), dim3(256), 0, S(st), (const bf16*)x, (const bf16*)res, \
-                       (bf16*)y, gamma, beta, running_mean, running_var, save_mean, save_invstd, (float*)ws, barrier, nvec, \
-                       C, relu, momentum, eps)
-    if (op.nv == 4) ONEPASS_FWD(4); else if (op.nv == 8) ONEPASS_FWD(8); else ONEPASS_FWD(16);
-#undef ONEPASS_FWD
-    DVAE_CHECK_LAUNCH("bn_onepass_fwd");
-    return DVAE_OK;
-}
-
-int dvae_bn_bwd_onepass(const void* dy, const void* y, const void* x, void* dx, void* dres, const float* gamma,
-                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* ws,
-                        size_t ws_bytes, unsigned* barrier, long rows, int C, int relu, int dtype, void* st) {
-    const OnepassPlan op = dtype == DVAE_BF16 ? onepass_plan(rows, C) : OnepassPlan{0, 0};
-    if (!op.nv) DVAE_FAIL(DVAE_EINVAL, "bn_bwd_onepass: %ld rows x %d channels (dtype %d) do not fit one grid "
-                                       "(see dvae_bn_onepass_blocks)", rows, C, dtype);
-    if (!dy || !x || !dx || !save_mean || !save_invstd || !ws || !barrier || (relu && !y))
-        DVAE_FAIL(DVAE_EINVAL, "bn_bwd_onepass: null argument");
-    if (ws_bytes < (size_t)op.blocks * 2 * C * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "bn_bwd_onepass: workspace too small");
-    const long nvec = rows * C / 8;
-#define ONEPASS_BWD(NV)                                                                                                \
-    hipLaunchKernelGGL((bn_onepass_bwd_kernel<NV>), dim3(op.blocks), dim3(256), 0, S(st), (const bf16*)dy, (const bf16*)y, \
-                       (const bf16*)x, (bf16*)dx, (bf16*)dres, gamma, save_mean, save_invstd, dgamma, dbeta, (float*)ws, \
-                       barrier, nvec, C, (float)rows, relu)
-    if (op.nv == 4) ONEPASS_BWD(4); else if (op.nv == 8) ONEPASS_BWD(8); else ONEPASS_BWD(16);
-#undef ONEPASS_BWD
-    DVAE_CHECK_LAUNCH("bn_onepass_bwd");
     return DVAE_OK;
 }
 

@@ -17,7 +17,6 @@ What it computes, by reference line:
 from __future__ import annotations
 
 import ctypes as C
-import os
 from dataclasses import dataclass
 
 import torch
@@ -270,9 +269,7 @@ class DVAEEngine:
         self.wgrad_ws_all = torch.empty(off, device=self.dev, dtype=torch.float32)
         self._reduce_jobs = {}        # batch size -> (job table on the device, jobs, widest job)
         self._batch_reduce = True
-        self.norm_ws = torch.empty(max(nb // 4 + 16, 256 * 3 * 256), device=self.dev, dtype=torch.float32)
-        self.bn_barrier = torch.zeros(4, device=self.dev, dtype=torch.int32)     # grid-barrier words of the one-launch BatchNorm
-        self._onepass = os.environ.get("DVAE_BN_ONEPASS", "1") != "0"
+        self.norm_ws = torch.empty(nb // 4 + 16, device=self.dev, dtype=torch.float32)
 
     def buf(self, name, shape, dtype=None):
         """Preallocated activation buffer (allocated on first use, then reused)."""
@@ -421,19 +418,8 @@ class DVAEEngine:
         check(self.lib.dvae_conv_wgrad(ptr(x), ptr(dy), ptr(self.grad[name + ".weight"]), ptr(db), ptr(self.wgrad_ws),
                                        self.wgrad_ws.numel() * 4, C.byref(self.desc(name, b)), self.dtype, L.stream()))
 
-    def _bn_onepass(self, rows, c):
-        """True where training BatchNorm runs as one launch each way (bf16 tensors that fit one grid's registers)."""
-        return (self._onepass and self.dtype == BF16 and self.lib.dvae_bn_onepass_blocks(rows, c, self.dtype) > 0)
-
     def _bn_train(self, name, x, y, rows, c, residual=None, relu=True):
         mean, invstd = self.bn_save[name]
-        if self._bn_onepass(rows, c):
-            check(self.lib.dvae_bn_fwd_train_onepass(
-                ptr(x), ptr(residual), ptr(y), ptr(self.param[name + ".weight"]), ptr(self.param[name + ".bias"]),
-                ptr(self.buffers[name + ".running_mean"]), ptr(self.buffers[name + ".running_var"]), ptr(mean), ptr(invstd),
-                ptr(self.norm_ws), self.norm_ws.numel() * 4, ptr(self.bn_barrier), rows, c, int(relu), BN_MOMENTUM, BN_EPS,
-                self.dtype, L.stream()))
-            return
         check(self.lib.dvae_norm_fwd_train(ptr(x), ptr(residual), ptr(y), ptr(self.param[name + ".weight"]),
                                            ptr(self.param[name + ".bias"]), ptr(self.buffers[name + ".running_mean"]),
                                            ptr(self.buffers[name + ".running_var"]), ptr(mean), ptr(invstd),
@@ -442,20 +428,10 @@ class DVAEEngine:
 
     def _bn_bwd(self, name, dy, y, x, dx, dres, rows, c, relu=True):
         mean, invstd = self.bn_save[name]
-        if self._bn_onepass(rows, c):
-            check(self.lib.dvae_bn_bwd_onepass(
-                ptr(dy), ptr(y), ptr(x), ptr(dx), ptr(dres), ptr(self.param[name + ".weight"]), ptr(mean), ptr(invstd),
-                ptr(self.grad[name + ".weight"]), ptr(self.grad[name + ".bias"]), ptr(self.norm_ws),
-                self.norm_ws.numel() * 4, ptr(self.bn_barrier), rows, c, int(relu), self.dtype, L.stream()))
-            return
         check(self.lib.dvae_norm_bwd(ptr(dy), ptr(y), ptr(x), ptr(dx), ptr(dres), ptr(self.param[name + ".weight"]),
                                      ptr(mean), ptr(invstd), ptr(self.grad[name + ".weight"]), ptr(self.grad[name + ".bias"]),
                                      ptr(self.norm_ws), self.norm_ws.numel() * 4, 1, rows, c, int(relu), self.dtype,
                                      L.stream()))
-
-    def barrier_timed_out(self):
-        """True if a one-launch BatchNorm ever gave up waiting for its grid (its results were invalid).  Synchronises."""
-        return bool(self.bn_barrier[2].item())
 
     def _in_fwd(self, tag, x, y, b, c):
         mean = self.buf(tag + ".mean", (self.B, c), torch.float32)

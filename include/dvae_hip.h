@@ -183,28 +183,6 @@ int dvae_norm_bwd(const void* dy, const void* y, const void* x,
                   void* workspace, size_t workspace_bytes,
                   int groups, int rows_per_group, int C, int relu, int dtype, void* stream);
 
-/* Training BatchNorm2d (+ residual) + ReLU of a bf16 tensor that fits the registers of one grid (at most 256 workgroups:
- * up to 8.4 M elements, e.g. batch 128 of 64 channels at 32x32), forward and backward as ONE launch each: every operand
- * is read once and every result written once, with a grid-wide barrier between the statistics and their use.  Same
- * arguments and results as dvae_norm_fwd_train / dvae_norm_bwd with groups = 1 (the 8 BatchNorm layers of a train step,
- * resnet.py:27-30 under main_vae_disentangle.py:180-211); sums are taken in a different (fixed) order, so results agree to
- * rounding, not bitwise.
- * dvae_bn_onepass_blocks: workgroups such a launch uses, 0 if the tensor does not fit (use the chunked entry points).
- * workspace: blocks * 3 * C floats (forward), blocks * 2 * C (backward).
- * barrier: 4 uint32 of device memory, ZERO before the first launch that uses them; launches re-arm them, so calls that
- * follow each other on one stream share them freely -- calls that may overlap on a device need words of their own.
- * barrier[2] != 0 afterwards: a workgroup waited for seconds without the others arriving and gave up; the results of
- * that launch are invalid. */
-int dvae_bn_onepass_blocks(long rows, int C, int dtype);
-int dvae_bn_fwd_train_onepass(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                              void* workspace, size_t workspace_bytes, unsigned* barrier,
-                              long rows, int C, int relu, float momentum, float eps, int dtype, void* stream);
-int dvae_bn_bwd_onepass(const void* dy, const void* y, const void* x, void* dx, void* dresidual,
-                        const float* gamma, const float* save_mean, const float* save_invstd,
-                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, unsigned* barrier,
-                        long rows, int C, int relu, int dtype, void* stream);
-
 /* ---- class embedding of decoder_p's input (resnet.py:2211-2221) ------------------------------ */
 /* emb [num_classes][C*HW] (reference layout, NCHW per class) -> table [class][px][c] in the act dtype */
 int dvae_emb_pack(const float* emb, void* table, int num_classes, int HW, int C, int spatial, int dtype, void* stream);

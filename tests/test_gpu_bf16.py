@@ -609,69 +609,3 @@ def test_post_conv_second_output_equals_embedding_add():
     # a conv that cannot do it must say so rather than drop the request
     d2 = L.ConvDesc(B, hw, hw, 128, 128, 3, 3, 1, 1, 0)
     assert lib.dvae_conv_supports_emb_out(C.byref(d2), L.BF16) == 0
-
-
-@pytest.mark.parametrize("B,hw,c,with_res", [(8, 32, 64, True), (128, 32, 64, True), (128, 16, 128, False), (3, 10, 32, True)])
-def test_batch_norm_one_launch_kernels_bf16(B, hw, c, with_res):
-    """Training BatchNorm(+residual)+ReLU as one launch each way (grid barrier, tensor in registers) against the chunked
-    three-launch kernels on the same inputs: statistics to fp32 rounding, bf16 outputs within one rounding step of each
-    other; then against torch autograd in fp32.  Two rounds in a row (the barrier re-arms itself), no wait timed out."""
-    lib = L.lib()
-    rows = B * hw * hw
-    assert lib.dvae_bn_onepass_blocks(rows, c, L.BF16) > 0
-    assert lib.dvae_bn_onepass_blocks(rows, c, L.F32) == 0 and lib.dvae_bn_onepass_blocks(2048 * 1024, 64, L.BF16) == 0
-    g = torch.Generator().manual_seed(c + B)
-    x = (torch.randn(B, c, hw, hw, generator=g) * 1.5 + 0.3).bfloat16().float()
-    r = torch.randn(B, c, hw, hw, generator=g).bfloat16().float() if with_res else None
-    dy = torch.randn(B, c, hw, hw, generator=g).bfloat16().float()
-    gamma = (torch.rand(c, generator=g) + 0.5).cuda()
-    beta = (torch.randn(c, generator=g) * 0.2).cuda()
-    xa, dya = to_act(x, L.BF16), to_act(dy, L.BF16)
-    ra = to_act(r, L.BF16) if with_res else None
-    ws = torch.empty(max(lib.dvae_norm_workspace_bytes(1, rows, c) // 4 + 16, 256 * 3 * 256), device="cuda")
-    barrier = torch.zeros(4, dtype=torch.int32, device="cuda")
-    st = L.stream()
-    out = {}
-    for kind in ("chunked", "onepass", "onepass2"):
-        ya, dxa, dra = torch.empty_like(xa), torch.empty_like(xa), torch.empty_like(xa)
-        mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
-        dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-        if kind == "chunked":
-            L.check(lib.dvae_norm_fwd_train(L.ptr(xa), L.ptr(ra), L.ptr(ya), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv),
-                                            L.ptr(mean), L.ptr(invstd), L.ptr(ws), ws.numel() * 4, 1, rows, c, 1, 0.1, 1e-5,
-                                            L.BF16, st))
-            L.check(lib.dvae_norm_bwd(L.ptr(dya), L.ptr(ya), L.ptr(xa), L.ptr(dxa), L.ptr(dra), L.ptr(gamma), L.ptr(mean),
-                                      L.ptr(invstd), L.ptr(dg), L.ptr(db), L.ptr(ws), ws.numel() * 4, 1, rows, c, 1, L.BF16, st))
-        else:
-            L.check(lib.dvae_bn_fwd_train_onepass(L.ptr(xa), L.ptr(ra), L.ptr(ya), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv),
-                                                  L.ptr(mean), L.ptr(invstd), L.ptr(ws), ws.numel() * 4, L.ptr(barrier), rows, c,
-                                                  1, 0.1, 1e-5, L.BF16, st))
-            L.check(lib.dvae_bn_bwd_onepass(L.ptr(dya), L.ptr(ya), L.ptr(xa), L.ptr(dxa), L.ptr(dra), L.ptr(gamma), L.ptr(mean),
-                                            L.ptr(invstd), L.ptr(dg), L.ptr(db), L.ptr(ws), ws.numel() * 4, L.ptr(barrier), rows,
-                                            c, 1, L.BF16, st))
-        torch.cuda.synchronize()
-        out[kind] = [t.float().cpu() for t in (ya, dxa, dra, mean, invstd, rm, rv, dg, db)]
-    assert barrier.tolist() == [0, 0, 0, 0]
-    for a, b in zip(out["onepass"], out["onepass2"]):
-        assert torch.equal(a, b)                           # deterministic, and the second round saw a re-armed barrier
-    ch, op = out["chunked"], out["onepass"]
-    for i in (3, 4, 5, 6):                                 # mean, invstd, running statistics
-        assert rel_err(op[i], ch[i]) < 2e-6
-    for i in (7, 8):                                       # dgamma, dbeta: fp32 sums of bf16 products in another order
-        assert rel_err(op[i], ch[i]) < 2e-5
-    assert torch.equal(op[2], ch[2])                       # the masked gradient handed to the residual branch: same bits
-    for i in (0, 1):                                       # bf16 outputs: a rounding step apart where the statistics' last bit matters
-        d = (op[i] - ch[i]).abs()
-        assert float((d > 0).float().mean()) < 0.02
-        assert float((d / (ch[i].abs() + 1e-3)).max()) < 2.0 ** -6
-    # against torch in fp32
-    xr = x.clone().requires_grad_(True)
-    rr = r.clone().requires_grad_(True) if with_res else None
-    pre = F.batch_norm(xr, None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
-    yr = F.relu(pre + rr if with_res else pre)
-    yr.backward(dy)
-    assert rel_err(from_act(out["onepass"][0], c), yr.detach()) < 6e-3
-    assert rel_err(from_act(out["onepass"][1], c), xr.grad) < 8e-3
-    if with_res:
-        assert rel_err(from_act(out["onepass"][2], c), rr.grad) < 6e-3
