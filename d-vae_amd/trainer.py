@@ -222,6 +222,41 @@ class VAE_Trainer:
         return out
 
 
+_STAGE = {}
+
+
+def _to_host_chunked(src, dst, chunk_rows=4096):
+    """Device tensor -> host tensor of the same shape (``dst``: pageable, any dtype), through two pinned staging buffers
+    that are kept for the life of the process: the device converts a chunk to ``dst``'s dtype and copies it out
+    asynchronously while the host moves the previous chunk from the staging buffer into ``dst``.  A pageable
+    ``tensor.cpu()`` of the 614 MB of perturbations of a 50 000-image pass takes 145 ms and its float64 conversion on
+    the host 25-40 more; this takes 35-45."""
+    n = src.shape[0]
+    if n == 0:
+        return dst
+    row = tuple(src.shape[1:])
+    key = (row, dst.dtype, chunk_rows)
+    if key not in _STAGE:
+        _STAGE[key] = [torch.empty((chunk_rows,) + row, dtype=dst.dtype, pin_memory=True) for _ in range(2)]
+    stage = _STAGE[key]
+    pending = []
+    for k, lo in enumerate(range(0, n, chunk_rows)):
+        hi = min(n, lo + chunk_rows)
+        if len(pending) == 2:                       # the buffer about to be reused must have been emptied
+            ev, plo, phi, ps = pending.pop(0)
+            ev.synchronize()
+            dst[plo:phi].copy_(ps[:phi - plo])
+        s = stage[k % 2]
+        s[:hi - lo].copy_(src[lo:hi], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((ev, lo, hi, s))
+    for ev, plo, phi, ps in pending:
+        ev.synchronize()
+        dst[plo:phi].copy_(ps[:phi - plo])
+    return dst
+
+
 @torch.no_grad()
 def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 0, device="cuda", act_dtype=None,
                    timings: dict | None = None):
@@ -268,10 +303,19 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 
     if timings is not None:
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-    dataset.data[...] = full_u8.cpu().numpy()
+    if full_u8.is_cuda:
+        _to_host_chunked(full_u8, torch.from_numpy(dataset.data))        # in place: main_vae_disentangle.py:67
+    else:
+        dataset.data[...] = full_u8.numpy()
     dataset.version = getattr(dataset, "version", 0) + 1      # loaders holding a device copy refresh it
     model_s.train(was_training)
-    res = full_noise.cpu().to(torch.float64) if full_noise is not None else None
+    res = None
+    if full_noise is not None:
+        res = torch.empty(full_noise.shape, dtype=torch.float64)
+        if full_noise.is_cuda:
+            _to_host_chunked(full_noise, res)
+        else:
+            res.copy_(full_noise)
     if timings is not None:
         t4 = time.perf_counter()
         timings.update(upload_s=t1 - t0, kernels_s=t2 - t1, gather_s=t3 - t2, host_tail_s=t4 - t3, total_s=t4 - t0)
