@@ -257,9 +257,52 @@ def _to_host_chunked(src, dst, chunk_rows=4096):
     return dst
 
 
+class _HostDrain:
+    """Copies finished batches of a purification pass to the host while later batches are still being computed (one
+    rank): for rows [lo, hi) the uint8 images go straight into ``dst_u8`` and the perturbations, converted to float64
+    on the device, into ``dst_f64``, each through pinned staging buffers on a copy stream of its own."""
+
+    DEPTH = 3
+
+    def __init__(self, dst_u8, dst_f64, rows, row_u8, row_f64):
+        self.dst = (dst_u8, dst_f64)
+        key = ("drain", rows, row_u8, row_f64)
+        if key not in _STAGE:
+            _STAGE[key] = [(torch.empty((rows,) + row_u8, dtype=torch.uint8, pin_memory=True),
+                            torch.empty((rows,) + row_f64, dtype=torch.float64, pin_memory=True)) for _ in range(self.DEPTH)]
+        self.stage = _STAGE[key]
+        self.stream = torch.cuda.Stream()
+        self.pending = []
+        self.k = 0
+
+    def _retire(self):
+        ev, lo, hi, st = self.pending.pop(0)
+        ev.synchronize()
+        for d, s in zip(self.dst, st):
+            d[lo:hi].copy_(s[:hi - lo])
+
+    def push(self, lo, hi, src_u8, src_noise):
+        """``src_*``: device tensors of the rows [lo, hi), complete once the current stream reaches this point."""
+        if len(self.pending) == self.DEPTH:
+            self._retire()
+        st = self.stage[self.k % self.DEPTH]
+        self.k += 1
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            st[0][:hi - lo].copy_(src_u8, non_blocking=True)
+            st[1][:hi - lo].copy_(src_noise, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.pending.append((ev, lo, hi, st))
+
+    def finish(self):
+        while self.pending:
+            self._retire()
+
+
 @torch.no_grad()
 def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 0, device="cuda", act_dtype=None,
-                   timings: dict | None = None):
+                   timings: dict | None = None, overlap_tail: bool = True):
     """The epoch-0 branch of ``Trainer.train`` (main_vae_disentangle.py:59-69) for a whole dataset:
     overwrites ``dataset.data`` in place with the purified uint8 images and returns the recorded
     perturbations as a float64 tensor [N,3,H,W] (on rank 0; the other ranks, which do not save it, get None).
@@ -292,30 +335,43 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 
     if timings is not None:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+    # One rank: finished batches drain to the host (dataset.data in place, main_vae_disentangle.py:67, and the float64
+    # perturbations) under the batches that follow.  Several ranks: gather first, then one chunked copy.
+    drain = None
+    if world == 1 and dev.type == "cuda" and overlap_tail:
+        res = torch.empty(n, 3, S, S, dtype=torch.float64)
+        drain = _HostDrain(torch.from_numpy(dataset.data), res, eng.B, tuple(data.shape[1:]), (3, S, S))
     for first in range(0, hi - lo, eng.B):
         b = min(eng.B, hi - lo - first)
         eng.purify_batch(data, out, noise, labels, first, b, stage, global_first=lo + first)
+        if drain is not None:
+            drain.push(first, first + b, out[first:first + b], noise[first:first + b])
     if timings is not None:
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-    full_u8 = D.all_gather_shards(out, n)
-    full_noise = D.gather_shards(noise, n, dst=0)
-    if timings is not None:
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-    if full_u8.is_cuda:
-        _to_host_chunked(full_u8, torch.from_numpy(dataset.data))        # in place: main_vae_disentangle.py:67
+    if drain is not None:
+        if timings is not None:
+            t3 = t2
+        drain.finish()
     else:
-        dataset.data[...] = full_u8.numpy()
+        full_u8 = D.all_gather_shards(out, n)
+        full_noise = D.gather_shards(noise, n, dst=0)
+        if timings is not None:
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+        if full_u8.is_cuda:
+            _to_host_chunked(full_u8, torch.from_numpy(dataset.data))
+        else:
+            dataset.data[...] = full_u8.numpy()
+        res = None
+        if full_noise is not None:
+            res = torch.empty(full_noise.shape, dtype=torch.float64)
+            if full_noise.is_cuda:
+                _to_host_chunked(full_noise, res)
+            else:
+                res.copy_(full_noise)
     dataset.version = getattr(dataset, "version", 0) + 1      # loaders holding a device copy refresh it
     model_s.train(was_training)
-    res = None
-    if full_noise is not None:
-        res = torch.empty(full_noise.shape, dtype=torch.float64)
-        if full_noise.is_cuda:
-            _to_host_chunked(full_noise, res)
-        else:
-            res.copy_(full_noise)
     if timings is not None:
         t4 = time.perf_counter()
         timings.update(upload_s=t1 - t0, kernels_s=t2 - t1, gather_s=t3 - t2, host_tail_s=t4 - t3, total_s=t4 - t0)
