@@ -280,7 +280,7 @@ static void wgrad_reduce_args(const WgradPlan& W, const dvae_conv_desc* d, const
     r.cx_log2 = W.cx_log2; r.Cd = W.Cd; r.ntaps = W.ntaps; r.sX = W.sX; r.sD = W.sD;
     memcpy(r.woff, W.woff, sizeof(r.woff));
     const long tot = (long)W.Kpad * W.CdPad;
-    r.nmain = (int)((tot + 63) / 64);
+    r.nmain = (int)((tot + 255) / 256);           // 256 slab elements per workgroup (wgrad_reduce_block)
     r.bpart = (const float*)ws + (size_t)W.S * W.Kpad * W.CdPad; r.db = db;
     r.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
     r.bwidth = wgrad_bias_width(W); r.Cb = d->Cout; r.cxs = W.CxS;
@@ -297,6 +297,7 @@ int dvae_conv_wgrad(const void* x, const void* dy, float* dw, float* db, void* w
     int rc = build_wgrad_plan(*d, dtype, W);
     if (rc) return rc;
     if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
+    if ((uintptr_t)ws & 15) DVAE_FAIL(DVAE_EINVAL, "wgrad workspace must be 16-byte aligned");
     const bool fused = db && wgrad_bias_fused(W);
     rc = wgrad_partials(W, d, x, dy, ws, fused, dtype, st);
     if (rc) return rc;
@@ -330,6 +331,7 @@ int dvae_conv_wgrad_partial(const void* x, const void* dy, int want_bias, void* 
     int rc = build_wgrad_plan(*d, dtype, W);
     if (rc) return rc;
     if (ws_bytes < wgrad_workspace_floats(W) * sizeof(float)) DVAE_FAIL(DVAE_EWORKSPACE, "wgrad workspace too small");
+    if ((uintptr_t)ws & 15) DVAE_FAIL(DVAE_EINVAL, "wgrad workspace must be 16-byte aligned");
     if (want_bias && !wgrad_bias_fused(W)) DVAE_FAIL(DVAE_EINVAL, "wgrad_partial: this shape's bias gradient needs dvae_conv_wgrad");
     return wgrad_partials(W, d, x, dy, ws, want_bias != 0, dtype, st);
 }
@@ -342,6 +344,7 @@ int dvae_wgrad_reduce_job(const void* ws, float* dw, float* db, const dvae_conv_
     int rc = build_wgrad_plan(*d, dtype, W);
     if (rc) return rc;
     if (db && !wgrad_bias_fused(W)) DVAE_FAIL(DVAE_EINVAL, "wgrad_reduce_job: this shape's bias gradient needs dvae_conv_wgrad");
+    if ((uintptr_t)ws & 15) DVAE_FAIL(DVAE_EINVAL, "wgrad_reduce_job: workspace must be 16-byte aligned");
     WreduceArgs r;
     wgrad_reduce_args(W, d, ws, dw, db, db != nullptr, r);
     memcpy(job_host, &r, sizeof(r));

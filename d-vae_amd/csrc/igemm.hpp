@@ -927,8 +927,6 @@ struct WreduceArgs {
 };
 
 __device__ __forceinline__ void wgrad_reduce_block(const WreduceArgs& a, const int bx) {
-    // 64 consecutive slab elements per block; 4 lanes split the S slabs (interleaved), each with
-    // independent loads in flight; the 4 partial sums are combined in lane order (deterministic).
     __shared__ float part[4][64];
     const long total = (long)a.Kpad * a.CdPad;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -962,20 +960,38 @@ __device__ __forceinline__ void wgrad_reduce_block(const WreduceArgs& a, const i
         }
         return;
     }
-    const long e = (long)bx * 64 + el;
-    float s0 = 0.f, s1 = 0.f;
+    // main part: 256 consecutive slab elements per block as 16-byte vectors, the 4 waves split the S slabs
+    // (interleaved), four loads of each in flight; partial sums combine in a fixed order (deterministic)
+    const long e = (long)bx * 256 + el * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (e < total) {
-        int i = sl;
-        for (; i + 4 < a.S; i += 8) { s0 += a.ws[(long)i * total + e]; s1 += a.ws[(long)(i + 4) * total + e]; }
-        if (i < a.S) s0 += a.ws[(long)i * total + e];
+        for (int i = sl; i < a.S; i += 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = i + 4 * u;
+                v[u] = *reinterpret_cast<const f32x4*>(a.ws + (long)(ii < a.S ? ii : i) * total + e);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + 4 * u < a.S) acc[u] += v[u];
+        }
     }
-    part[sl][el] = s0 + s1;
+    __shared__ f32x4 part4[4][64];
+    part4[sl][el] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
     if (sl != 0 || e >= total) return;
-    const int k = (int)(e / a.CdPad), cd = (int)(e % a.CdPad);
-    const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
-    if (tap >= a.ntaps || c >= a.Cx || cd >= a.Cd) return;
-    a.dw[(long)cd * a.sD + (long)c * a.sX + a.woff[tap]] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    const f32x4 t = (part4[0][el] + part4[1][el]) + (part4[2][el] + part4[3][el]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long eq = e + q;
+        const int k = (int)(eq / a.CdPad), cd = (int)(eq % a.CdPad);
+        const int tap = k >> a.cx_log2, c = k & ((1 << a.cx_log2) - 1);
+        if (tap >= a.ntaps || c >= a.Cx || cd >= a.Cd) continue;
+        a.dw[(long)cd * a.sD + (long)c * a.sX + a.woff[tap]] = t[q];
+    }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) { wgrad_reduce_block(a, (int)blockIdx.x); }

@@ -112,7 +112,7 @@ int dvae_conv_supports_input_norm(const dvae_conv_desc* d, int dtype);
 int dvae_conv_supports_emb_out(const dvae_conv_desc* d, int dtype);
 int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int accumulate,
                     const dvae_conv_desc* d, int dtype, void* stream);
-size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);
+size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);   /* the workspace must be 16-byte aligned */
 int dvae_conv_wgrad(const void* x, const void* dy, float* dw_ref, float* db_ref /* or NULL */,
                     void* workspace, size_t workspace_bytes, const dvae_conv_desc* d, int dtype, void* stream);
 /* The same gradient in two steps, so that a backward pass reduces the slabs of ALL its convs in one launch (autograd
