@@ -7,6 +7,7 @@
 #include "conv_wreg.hpp"
 #include "conv_image.hpp"
 #include "wgrad_halo.hpp"
+#include "wgrad_big.hpp"
 #include "conv_stem.hpp"
 #include "conv_point.hpp"
 #include "norm.hpp"
@@ -266,6 +267,8 @@ static int wgrad_partials(const WgradPlan& W, const dvae_conv_desc* d, const voi
         hipLaunchKernelGGL(wgrad_halo_bf16_kernel, dim3(W.S), dim3(256), WH_LDS, S(st), h);
     } else if (dtype == DVAE_F32)
         hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
+    else if (W.big)
+        launch_wgrad_big(a, W.S, S(st));
     else
         hipLaunchKernelGGL(wgrad_kernel_bf16, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
     DVAE_CHECK_LAUNCH("wgrad");

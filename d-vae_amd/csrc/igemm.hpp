@@ -642,7 +642,16 @@ struct WgradPlan {
     int bias_from_gathered;         // bias gradient = column sums of the gathered (1) or dense (0) tensor
     unsigned bias_taps;             // gathered case: the taps that together read every pixel exactly once (0: none known)
     int halo, halo_tiles, halo_per; // all-taps-per-tile kernel (wgrad_halo.hpp): S workgroups of halo_per 4 x 32 tiles
+    int big;                        // large-tile kernel (wgrad_big.hpp): every other bf16 launch
 };
+
+// tile of the large-tile kernel for a slab of Kpad x CdPad: {K width, Cd width}, always 8 waves of 64 x 64
+struct WgradBigTile { int tk, tc; };
+static inline WgradBigTile wgrad_big_tile(int Kpad, int CdPad) {
+    if (CdPad <= 64) return {512, 64};
+    if (Kpad <= 128) return {128, 256};
+    return {256, 128};
+}
 
 static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     GemmPlan P;
@@ -681,6 +690,20 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     const int tiles = (W.Kpad / 64) * (W.CdPad / 64);
     int S = 768 / tiles; if (S < 1) S = 1;
     int chunk = round_up((W.M + S - 1) / S, 64); if (chunk < 64) chunk = 64;
+    // Large tiles (wgrad_big.hpp) where the slab is wide both ways -- the 128-channel 3x3 / 4x4 shapes: 380 -> 233, 204 ->
+    // 152 and 275 -> 254 us per 1024 images.  Narrow slabs read little to begin with and are bound by the per-row
+    // address arithmetic, which the large-tile kernel spreads over fewer waves: they stay on the 64 x 64 tiles.
+    if (dtype == DVAE_BF16 && W.Kpad >= 512 && W.CdPad >= 128) {
+        // one workgroup per CU where the pixels allow it, at least 16 stages of 64 rows each (a workgroup leaves a
+        // whole tile per chunk for the reduction to read back)
+        const WgradBigTile t = wgrad_big_tile(W.Kpad, W.CdPad);
+        const int cols = ((W.Kpad + t.tk - 1) / t.tk) * ((W.CdPad + t.tc - 1) / t.tc);
+        S = 256 / cols;
+        if (S > W.M / 1024) S = W.M / 1024;
+        if (S < 1) S = 1;
+        chunk = round_up((W.M + S - 1) / S, 64);
+        W.big = 1;
+    }
     W.chunk_rows = chunk;
     W.S = (W.M + chunk - 1) / chunk;
     // 3x3 unit-stride 64 -> 64 in bf16: one staged tile serves all nine taps.  Each workgroup leaves a 147 KB slab for
@@ -689,7 +712,7 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     bool halo = dtype == DVAE_BF16 && kk == 9 && s == 1 && p == 1 && W.CxS == 64 && W.CdS == 64 && W.Hx == W.Hg && W.Wx == W.Wg &&
                 W.Wg % 32 == 0 && W.Hg % 4 == 0 && (long)W.M * 64 <= 0x7fffffffL;
     if (halo) {
-        W.halo = 1;
+        W.halo = 1; W.big = 0;
         W.halo_tiles = d.B * (W.Hg / 4) * (W.Wg / 32);
         int g = W.halo_tiles / 8;
         if (g > 256) g = 256;
