@@ -132,25 +132,24 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partial
     const int c = blockIdx.x * 8 + cl;
     float n = 0.f, m = 0.f, q = 0.f;
     if (c < C) {
-        // four chunks per trip, their loads issued together (the merge order is unchanged: a serial chain over ch)
-        for (int ch0 = lane32; ch0 < nchunk; ch0 += 128) {
-            float pn[4], pm[4], pq[4];
+        // sixteen chunks per trip, their loads issued together: up to 512 chunks are one round trip to memory instead of
+        // four dependent ones (the merge order is unchanged: a serial chain over ch)
+        constexpr int U = 16;
+        for (int ch0 = lane32; ch0 < nchunk; ch0 += 32 * U) {
+            float pn[U], pm[U], pq[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ch = ch0 + 32 * u;
-                pn[u] = 0.f; pm[u] = 0.f; pq[u] = 0.f;
-                if (ch < nchunk) {
-                    if (chunk_rows > 0) {
-                        const float* p = partial + ((long)(g * nchunk + ch) * 2) * C + c;
-                        pn[u] = (float)chunk_rows; pm[u] = p[0]; pq[u] = p[C];
-                    } else {
-                        const float* p = partial + ((long)(g * nchunk + ch) * 3) * C + c;
-                        pn[u] = p[0]; pm[u] = p[C]; pq[u] = p[2 * C];
-                    }
+            for (int u = 0; u < U; ++u) {
+                const int ch = ch0 + 32 * u < nchunk ? ch0 + 32 * u : ch0;   // (past the end: a chunk again, not merged below;
+                if (chunk_rows > 0) {                                        // a load inside a branch would be waited for there)
+                    const float* p = partial + ((long)(g * nchunk + ch) * 2) * C + c;
+                    pn[u] = (float)chunk_rows; pm[u] = p[0]; pq[u] = p[C];
+                } else {
+                    const float* p = partial + ((long)(g * nchunk + ch) * 3) * C + c;
+                    pn[u] = p[0]; pm[u] = p[C]; pq[u] = p[2 * C];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (ch0 + 32 * u >= nchunk) break;
                 if (chunk_rows > 0) {
                     const float mean = pm[u] / pn[u], m2 = pq[u] - pm[u] * mean;
@@ -343,16 +342,16 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* par
     const int c = blockIdx.x * 8 + cl;
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
-        for (int ch0 = lane32; ch0 < nchunk; ch0 += 128) {     // four loads in flight, summed in chunk order
-            float p1[4], p2[4];
+        for (int ch0 = lane32; ch0 < nchunk; ch0 += 512) {     // sixteen loads in flight, summed in chunk order
+            float p1[16], p2[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int ch = ch0 + 32 * u;
                 const float* p = partial + ((long)(g * nchunk + (ch < nchunk ? ch : ch0)) * 2) * C + c;
                 p1[u] = p[0]; p2[u] = p[C];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (ch0 + 32 * u < nchunk) { s1 += p1[u]; s2 += p2[u]; }
         }
     }
