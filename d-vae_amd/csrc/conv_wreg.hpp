@@ -22,8 +22,11 @@
 // accumulator file as spill space (four v_accvgpr_read per MFMA); the "a" constraint pins the weights there.  hipcc pads no
 // hazards for an asm statement: an accumulator set is first read by the epilogue at least four MFMAs after its last write
 // (G_MIN), and the tail code waits explicitly.
-// Serves the same plans as conv_halo.hpp's plain instantiation with 32-pixel-wide tiles: Conv2d 3x3 s1 forward and
-// input-gradient, ConvTranspose2d 3x3 s1 forward and input-gradient, bf16 output.
+// Serves the plans of conv_halo.hpp's plain instantiation that have 64 input channels and 32-pixel-wide tiles: Conv2d 3x3
+// s1 forward and input-gradient, ConvTranspose2d 3x3 s1 forward and input-gradient, bf16 output.
+// Measured (64 -> 64 at 32x32, 1024 images per launch): 72 us against 93 us for conv_halo.hpp when either kernel runs
+// alone in a loop, 5 870 against 7 900 shader cycles per tile; inside the purification step, where every launch around it
+// is as dense, the card settles at a lower clock and both take 79 us.
 #pragma once
 #include <math.h>
 
@@ -188,13 +191,6 @@ __host__ __device__ constexpr WregSched<2 * G> wreg_make_sched() {
         if (s.over == 0) return s;
     }
     return wreg_try_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD>(16);
-}
-
-// max(f, lo) as ONE instruction (fmaxf costs a second v_max that quiets signalling NaNs first)
-__device__ __forceinline__ float vmax1(float f, float lo) {
-    float o;
-    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(f), "v"(lo));
-    return o;
 }
 
 // WTL: the last WTL taps' fragments are held in architectural VGPRs instead of the accumulator file (64 -> 64: nine taps
