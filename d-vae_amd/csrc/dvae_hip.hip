@@ -258,13 +258,20 @@ static int wgrad_partials(const WgradPlan& W, const dvae_conv_desc* d, const voi
     a.bias_mode = !fused ? 0 : W.bias_from_gathered ? 2 : 1;
     a.bias_taps = W.bias_taps; a.bpart = (float*)ws + (size_t)W.S * W.Kpad * W.CdPad;
     if (W.halo) {
-        static LdsOptIn lds_opt;
-        lds_opt.ensure(reinterpret_cast<const void*>(&wgrad_halo_bf16_kernel), WH_LDS);
         WgradHaloArgs h;
         h.xg = (const bf16*)a.xg; h.d = (const bf16*)a.d; h.ws = a.ws;
         h.H = W.Hg; h.W = W.Wg; h.tiles_x = W.Wg / 32; h.tiles_y = W.Hg / 4; h.ntiles = W.halo_tiles; h.per = W.halo_per;
+        h.Kpad = W.Kpad; h.CdPad = W.CdPad;
         h.bias_mode = a.bias_mode; h.bpart = a.bpart;
-        hipLaunchKernelGGL(wgrad_halo_bf16_kernel, dim3(W.S), dim3(256), WH_LDS, S(st), h);
+        const int wgs = W.S / W.halo_groups;
+#define WGRAD_HALO_CASE(CX_, CD_)                                                                                  \
+        if (W.CxS == CX_ && W.CdS == CD_) {                                                                        \
+            static LdsOptIn lds_opt;                                                                               \
+            lds_opt.ensure(reinterpret_cast<const void*>(&wgrad_halo_bf16_kernel<CX_, CD_>), WH_LDS);              \
+            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<CX_, CD_>), dim3(wgs), dim3(256), WH_LDS, S(st), h);        \
+        }
+        WGRAD_HALO_CASE(64, 64) WGRAD_HALO_CASE(32, 64) WGRAD_HALO_CASE(8, 64) WGRAD_HALO_CASE(8, 32)
+#undef WGRAD_HALO_CASE
     } else if (dtype == DVAE_F32)
         hipLaunchKernelGGL(wgrad_kernel_f32, dim3(W.S, W.Kpad / 64, W.CdPad / 64), dim3(256), 0, S(st), a);
     else if (W.big)

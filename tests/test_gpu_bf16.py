@@ -289,7 +289,9 @@ def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
 
 BACKWARD = [
     (64, 64, 3, 1, 1, False, 32),       # all-tap weight gradient; halo kernel as input-gradient
-    (64, 32, 3, 1, 1, True, 32),
+    (64, 32, 3, 1, 1, True, 32),        # all-tap weight gradient, 32 x 64 stored channels: two pixel-row groups per workgroup
+    (32, 3, 3, 1, 1, True, 32),         # ... 8 x 32: four row groups
+    (3, 64, 3, 1, 1, False, 32),        # ... 8 x 64 (the first conv)
     (64, 128, 3, 2, 1, False, 32),      # slab weight gradient; image-resident input-gradient (9 slabs)
     (128, 64, 4, 2, 1, True, 16),
     (128, 128, 3, 1, 1, False, 16),
