@@ -263,7 +263,7 @@ static int wgrad_partials(const WgradPlan& W, const dvae_conv_desc* d, const voi
         h.H = W.Hg; h.W = W.Wg; h.tiles_x = W.Wg / 32; h.tiles_y = W.Hg / 4; h.ntiles = W.halo_tiles; h.per = W.halo_per;
         h.Kpad = W.Kpad; h.CdPad = W.CdPad;
         h.bias_mode = a.bias_mode; h.bpart = a.bpart;
-        const int wgs = W.S / W.halo_groups;
+        const int wgs = W.S;
 #define WGRAD_HALO_CASE(CX_, CD_)                                                                                  \
         if (W.CxS == CX_ && W.CdS == CD_) {                                                                        \
             static LdsOptIn lds_opt;                                                                               \

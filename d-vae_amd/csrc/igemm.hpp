@@ -641,8 +641,7 @@ struct WgradPlan {
     int M, S, chunk_rows, Kpad, CdPad;
     int bias_from_gathered;         // bias gradient = column sums of the gathered (1) or dense (0) tensor
     unsigned bias_taps;             // gathered case: the taps that together read every pixel exactly once (0: none known)
-    int halo, halo_tiles, halo_per; // all-taps-per-tile kernel (wgrad_halo.hpp): workgroups of halo_per 4 x 32 tiles,
-    int halo_groups;                // each leaving halo_groups slabs (S = workgroups * halo_groups)
+    int halo, halo_tiles, halo_per; // all-taps-per-tile kernel (wgrad_halo.hpp): S workgroups of halo_per 4 x 32 tiles
     int big;                        // large-tile kernel (wgrad_big.hpp): every other bf16 launch
 };
 
@@ -710,8 +709,7 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     // 3x3 unit-stride in bf16 with 64 x 64, 32 x 64, 8 x 64 or 8 x 32 stored channels (gathered x dense): one staged tile
     // serves all nine taps (wgrad_halo.hpp).  Each workgroup leaves whole slabs for the reduction to read back (147 KB for
     // 64 x 64), so at least 8 tiles each once there are enough (batch 128: one workgroup per two CUs), at most one
-    // workgroup per CU; shapes whose taps have fewer than four 32 x 32 quadrants split a tile's pixel rows over the waves
-    // and leave one slab per row group.
+    // workgroup per CU.
     const bool halo_cc = (W.CxS == 64 && W.CdS == 64) || (W.CxS == 32 && W.CdS == 64) || (W.CxS == 8 && W.CdS == 64) ||
                          (W.CxS == 8 && W.CdS == 32);
     bool halo = dtype == DVAE_BF16 && kk == 9 && s == 1 && p == 1 && halo_cc && W.Hx == W.Hg && W.Wx == W.Wg &&
@@ -724,8 +722,7 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
         if (g < 1) g = 1;
         W.halo_per = (W.halo_tiles + g - 1) / g;
         W.halo_per += W.halo_per & 1;                  // the kernel walks its tiles two at a time
-        W.halo_groups = 4 / ((W.CxS >= 32 ? W.CxS / 32 : 1) * (W.CdS >= 32 ? W.CdS / 32 : 1));
-        W.S = (W.halo_tiles + W.halo_per - 1) / W.halo_per * W.halo_groups;
+        W.S = (W.halo_tiles + W.halo_per - 1) / W.halo_per;
     }
     return DVAE_OK;
 }

@@ -8,7 +8,8 @@
 // CX x CD output of a tap into 32 x 32 quadrants (64 x 64: 2 x 2) and, where a tap has fewer than four quadrants, the
 // tile's four pixel rows among themselves (32 x 64: two quadrants x two row pairs; 8 x 32: one quadrant x four rows);
 // each wave keeps its quadrant of all nine taps in 144 accumulator registers for its whole run of tiles, so the only
-// output is one [9 CX][CD] fp32 slab per workgroup and pixel-row group, in the layout wgrad_reduce_kernel sums.  LDS
+// output is one [9 CX][CD] fp32 slab per workgroup (row groups add their accumulators through LDS at the end), in the
+// layout wgrad_reduce_kernel sums.  LDS
 // is double-buffered and the registers run two tiles ahead: a tile's rows are fetched into one of two register sets
 // before the MFMA loop of the tile two before it (one loop, 1.1 us, is shorter than a memory round trip under load) and
 // written to the idle LDS buffer after the loop of the tile before it; one barrier per tile.
@@ -24,7 +25,7 @@ namespace dvae {
 struct WgradHaloArgs {
     const bf16* xg;            // gathered tensor [B][H][W][CX]
     const bf16* d;             // dense tensor    [B][H][W][CD]
-    float* ws;                 // [gridDim.x * row groups][Kpad][CdPad]
+    float* ws;                 // [gridDim.x][Kpad][CdPad]
     int H, W, tiles_x, tiles_y, ntiles, per;   // tiles of 4 x 32 pixels; `per` consecutive tiles per workgroup
     int Kpad, CdPad;           // slab dimensions (9 CX and CD rounded up to 64)
     int bias_mode;             // 0 none, 1 column sums of d, 2 column sums of xg (its centre tap reads each pixel once)
@@ -33,9 +34,6 @@ struct WgradHaloArgs {
 
 constexpr int WH_RS = 192, WH_HP = 6 * 34, WH_XB = WH_HP * WH_RS, WH_DB = 128 * WH_RS, WH_BUF = WH_XB + WH_DB;
 constexpr int WH_LDS = 2 * WH_BUF;
-
-// pixel-row groups a workgroup's waves split a tile into (= slabs per workgroup)
-static constexpr int wgrad_halo_row_groups(int CX, int CD) { return 4 / ((CX >= 32 ? CX / 32 : 1) * (CD >= 32 ? CD / 32 : 1)); }
 
 template <int CX, int CD>
 __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArgs a) {
@@ -172,11 +170,34 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
         tile_step(t + 1, std::integral_constant<int, 1>{});
     }
 
-    // ---- slab (blockIdx.x, wp): rows tap * CX + channel, the channels of this wave's quadrant that exist ----
+    // ---- the pixel-row groups' accumulators are summed through LDS (fixed order), so a workgroup leaves ONE slab ----
+    float* red = reinterpret_cast<float*>(smem);        // every wave is past the last barrier of the tile loop
+    if (WPN > 1) {
+        static_assert((4 - WIN * WJN) * 9 * 16 * 64 * 4 <= WH_LDS, "accumulator exchange fits the tile buffers");
+        if (wp > 0) {
+            float* o = red + (long)(wave - WIN * WJN) * (9 * 16 * 64) + lane;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[(tap * 16 + e) * 64] = acc[tap][e];
+        }
+        __syncthreads();
+        if (wp == 0) {
+#pragma unroll
+            for (int g = 1; g < WPN; ++g) {
+                const float* o = red + (long)(wave + (g - 1) * WIN * WJN) * (9 * 16 * 64) + lane;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[tap][e] += o[(tap * 16 + e) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- slab blockIdx.x: rows tap * CX + channel, the channels of this wave's quadrant that exist ----
     const int r = lane & 31, h = lane >> 5;
-    const long slab = (long)blockIdx.x * WPN + wp;
-    if (wj * 32 + r < CD) {
-        float* ws = a.ws + slab * a.Kpad * a.CdPad + wj * 32 + r;
+    if (wp == 0 && wj * 32 + r < CD) {
+        float* ws = a.ws + (long)blockIdx.x * a.Kpad * a.CdPad + wj * 32 + r;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -185,8 +206,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
                 if (cx < CX) ws[(long)(tap * CX + cx) * a.CdPad] = acc[tap][e];
             }
     }
-    // ---- bias partial sums: one row per slab; the workgroup's sums go to its first slab, zeros to the others ----
-    float* red = reinterpret_cast<float*>(smem);        // every wave is past the last barrier of the tile loop
+    // ---- bias partial sums: one row per slab ----
     if (a.bias_mode == 1) {
         constexpr int RL = 256 / VD;
 #pragma unroll
@@ -195,9 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
         if (tid < CD) {
             float t = 0.f;
             for (int q = 0; q < RL; ++q) t += red[q * CD + tid];
-            a.bpart[(long)blockIdx.x * WPN * a.CdPad + tid] = t;
-#pragma unroll
-            for (int g = 1; g < WPN; ++g) a.bpart[((long)blockIdx.x * WPN + g) * a.CdPad + tid] = 0.f;
+            a.bpart[(long)blockIdx.x * a.CdPad + tid] = t;
         }
     }
     if (a.bias_mode == 2) {
@@ -208,9 +226,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_bf16_kernel(const WgradHaloArg
         if (tid < CX) {
             float t = 0.f;
             for (int q = 0; q < RL; ++q) t += red[q * CX + tid];
-            a.bpart[(long)blockIdx.x * WPN * a.Kpad + 4 * CX + tid] = t;
-#pragma unroll
-            for (int g = 1; g < WPN; ++g) a.bpart[((long)blockIdx.x * WPN + g) * a.Kpad + 4 * CX + tid] = 0.f;
+            a.bpart[(long)blockIdx.x * a.Kpad + 4 * CX + tid] = t;
         }
     }
 }
