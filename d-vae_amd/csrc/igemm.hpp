@@ -648,9 +648,8 @@ struct WgradPlan {
 // tile of the large-tile kernel for a slab of Kpad x CdPad: {K width, Cd width}, always 8 waves of 64 x 64
 struct WgradBigTile { int tk, tc; };
 static inline WgradBigTile wgrad_big_tile(int Kpad, int CdPad) {
-    if (CdPad <= 64) return {512, 64};
-    if (Kpad <= 128) return {128, 256};
-    return {256, 128};
+    (void)Kpad; (void)CdPad;
+    return {256, 128};              // (512 x 64 and 128 x 256 were built too: narrow slabs are not bandwidth-bound, see below)
 }
 
 static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {

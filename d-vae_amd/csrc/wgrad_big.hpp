@@ -3,7 +3,7 @@
 // The 64 x 64-tile kernel of igemm.hpp (wgrad_kernel_bf16) re-reads its pixel rows once per tile column: for the
 // 128 -> 128 3x3 conv of layer2 that is 2.4 GB through L2 for 134 MB of operands, and the launch runs at the rate L2
 // delivers them (6 TB/s), 0.2 PFLOP/s.  Here a workgroup of 8 waves owns a tile of (64 KW) x (64 CW) slab elements -- 256
-// x 128, 512 x 64 or 128 x 256 -- so a launch has 3 to 8 times fewer tile columns and reads that much less; a wave owns
+// x 128 as instantiated -- so a launch has 3 to 5 times fewer tile columns and reads that much less; a wave owns
 // 64 x 64 of the tile (four accumulators: 1 KB of LDS reads per MFMA instead of 2).  MS pixel rows per stage, two LDS
 // stages, and a ring of three stages of rows in flight in registers: every row is fetched three stages ahead, written to
 // the idle LDS buffer one stage ahead, and a stage costs one barrier.  Loads are unconditional (clamped address, rows that
@@ -217,7 +217,7 @@ static void launch_wgrad_big(const WgradArgs& a, int S, hipStream_t st) {
         hipLaunchKernelGGL((wgrad_big_bf16_kernel<KW, CW, MS>), grid, block, lds, st, a);                       \
         return;                                                                                                 \
     }
-    WGRAD_BIG_CASE(8, 1, 32) WGRAD_BIG_CASE(2, 4, 64) WGRAD_BIG_CASE(4, 2, 64)
+    WGRAD_BIG_CASE(4, 2, 64)
 #undef WGRAD_BIG_CASE
 }
 
