@@ -691,8 +691,9 @@ static int build_wgrad_plan(const dvae_conv_desc& d, int dtype, WgradPlan& W) {
     int chunk = round_up((W.M + S - 1) / S, 64); if (chunk < 64) chunk = 64;
     // Large tiles (wgrad_big.hpp) where the slab is wide both ways -- the 128-channel 3x3 / 4x4 shapes: 380 -> 233, 204 ->
     // 152 and 275 -> 254 us per 1024 images.  Narrow slabs read little to begin with and are bound by the per-row
-    // address arithmetic, which the large-tile kernel spreads over fewer waves: they stay on the 64 x 64 tiles.
-    if (dtype == DVAE_BF16 && W.Kpad >= 512 && W.CdPad >= 128) {
+    // address arithmetic, which the large-tile kernel spreads over fewer waves: they stay on the 64 x 64 tiles.  So do
+    // small launches (batch 128 of 16 x 16 maps is 32 768 rows: 16 stages per large tile, 40 against 28 us).
+    if (dtype == DVAE_BF16 && W.Kpad >= 512 && W.CdPad >= 128 && W.M >= 100000) {
         // one workgroup per CU where the pixels allow it, at least 16 stages of 64 rows each (a workgroup leaves a
         // whole tile per chunk for the reduction to read back)
         const WgradBigTile t = wgrad_big_tile(W.Kpad, W.CdPad);
