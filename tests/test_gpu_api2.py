@@ -421,3 +421,25 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
     print("clean test accuracy after training on purified data:", accs)
     assert accs["oracle"] > 90.0, accs
     assert abs(accs["f32"] - accs["oracle"]) <= 1.0 and abs(accs["bf16"] - accs["oracle"]) <= 1.0, accs
+
+
+def test_device_to_host_staging_is_exact():
+    """The chunked pinned-buffer copy of purify_dataset's tail (ragged last chunk, dtype conversion on the device, more
+    chunks than staging buffers) and the per-batch drain give the bytes of a plain .cpu()."""
+    from dvae_amd import trainer as T
+    g = torch.Generator(device="cuda").manual_seed(3)
+    src = torch.randn(53, 3, 8, 8, generator=g, device="cuda")
+    dst = torch.empty(53, 3, 8, 8, dtype=torch.float64)
+    T._to_host_chunked(src, dst, chunk_rows=7)
+    assert torch.equal(dst, src.cpu().double())
+    u8 = torch.randint(0, 256, (53, 8, 8, 3), generator=g, dtype=torch.uint8, device="cuda")
+    d8 = torch.zeros(53, 8, 8, 3, dtype=torch.uint8)
+    T._to_host_chunked(u8, d8, chunk_rows=16)
+    assert torch.equal(d8, u8.cpu())
+    d8.zero_(); dst.zero_()
+    drain = T._HostDrain(d8, dst, 10, (8, 8, 3), (3, 8, 8))
+    for lo in range(0, 53, 10):                                  # six batches through three staging buffers
+        hi = min(53, lo + 10)
+        drain.push(lo, hi, u8[lo:hi], src[lo:hi])
+    drain.finish()
+    assert torch.equal(d8, u8.cpu()) and torch.equal(dst, src.cpu().double())
