@@ -122,6 +122,7 @@ def test_losses_and_gradients(golden_dir, name):
     eng.forward(x0, y.cuda(), e, 4, True)
     # ReLU gradients are discontinuous at 0: differentiate the oracle with the engine's masks
     masks, flips = engine_relu_masks(eng, 4, ocfg, p, x, y, eps)
+    print(f"ReLU mask flips against the oracle, scenario {name}: {flips}")     # (pytest -s shows it)
     pc = {k: v.clone() for k, v in p.items()}
     info, grads, _ = O.train_step(pc, ocfg, x, y, eps, {}, epoch, stage, masks=masks)
     eng.loss_sums()
