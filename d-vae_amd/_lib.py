@@ -48,6 +48,7 @@ _SIGS = {
     "dvae_conv_dgrad": (C.c_int, [_P, _P, _P, _I, C.POINTER(ConvDesc), _I, _P]),
     "dvae_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "dvae_conv_wgrad": (C.c_int, [_P, _P, _P, _P, _P, _Z, C.POINTER(ConvDesc), _I, _P]),
+    "dvae_conv_wgrad_uses_big_tiles": (C.c_int, [C.POINTER(ConvDesc), _I]),
     "dvae_conv_wgrad_partial": (C.c_int, [_P, _P, _I, _P, _Z, C.POINTER(ConvDesc), _I, _P]),
     "dvae_wgrad_reduce_job_bytes": (_Z, []),
     "dvae_wgrad_reduce_job": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _I, _P, C.POINTER(C.c_int)]),
@@ -74,7 +75,7 @@ _SIGS = {
     "dvae_loss_gate": (C.c_int, [_P, _P, _D, _D, _D, _D, _F, _F, _I, _P]),
     "dvae_recon_loss_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dvae_purify_quant": (C.c_int, [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P]),
-    "dvae_poison_u8": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
+    "dvae_poison_u8": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "dvae_sqnorm_partial": (C.c_int, [_P, _L, _P, _P]),
     "dvae_clip_adam": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
 }

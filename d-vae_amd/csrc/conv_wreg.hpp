@@ -583,7 +583,10 @@ static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* 
                                  unsigned long long* stamps = nullptr) {
     // (ReLU before the addition of the old output is the one order this kernel does not have; nothing asks for it)
     if (out_f32 || !wreg_applicable(P) || (res && accumulate) || (relu && accumulate)) return false;
-    if ((long)P.B * P.Hout * P.Wout * (P.CgS > P.NS ? P.CgS : P.NS) * 2 >= 0xfffffff0L) return false;
+    // Bit 31 of a lane's input offset is the "return zeros" marker and the tile origins are 32-bit byte offsets: tensors
+    // stay below 2 GB less the descriptor's lead-in (16 384 images of 32 x 32 x 64 and more go to the LDS-weights kernel).
+    if ((long)P.B * P.Hout * P.Wout * (P.CgS > P.NS ? P.CgS : P.NS) * 2 >= 0x80000000L - (long)(P.Wout + 1) * P.CgS * 2 - 16)
+        return false;
     const HaloGeom hg = halo_geom(P);
     const Phase& ph = P.ph[0];
     const int NT = hg.NT;

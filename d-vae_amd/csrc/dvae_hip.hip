@@ -242,6 +242,12 @@ size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d) {
     return (a > b ? a : b) * sizeof(float);
 }
 
+int dvae_conv_wgrad_uses_big_tiles(const dvae_conv_desc* d, int dtype) {
+    WgradPlan W;
+    if (!d || build_wgrad_plan(*d, dtype, W)) return 0;
+    return W.big ? 1 : 0;
+}
+
 // slab (and bias-partial) launches of one weight gradient into ws; fused: the bias partials ride along
 static int wgrad_partials(const WgradPlan& W, const dvae_conv_desc* d, const void* x, const void* dy, void* ws, bool fused,
                           int dtype, void* st) {
@@ -720,10 +726,10 @@ int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out, 
 
 // ---------------------------------------------------------------------------------------------
 int dvae_poison_u8(const uint8_t* src, const float* pert, const int64_t* labels, const uint8_t* mask, uint8_t* dst,
-                   int64_t N, int HW, void* st) {
+                   int64_t N, int HW, int prescaled, void* st) {
     if (!src || !pert || !dst || N <= 0 || HW <= 0) DVAE_FAIL(DVAE_EINVAL, "poison_u8: null argument / empty");
     hipLaunchKernelGGL(poison_u8_kernel, dim3(grid_for((long)N * HW)), dim3(256), 0, S(st), src, pert, labels, mask, dst,
-                       (long)N, HW);
+                       (long)N, HW, prescaled);
     DVAE_CHECK_LAUNCH("poison_u8");
     return DVAE_OK;
 }

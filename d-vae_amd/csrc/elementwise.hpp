@@ -388,10 +388,12 @@ __global__ void purify_quant_kernel(const TA* a, int CSA, const float* b, int CS
 // unlearnable-example ingress: data = uint8(clip(float(data) + clamp(255 * perturbation, -255, 255), 0, 255))
 // (PoisonCIFAR10, dataset.py:1235, :1287-1289).  perturbation is fp32 NCHW, one image per sample
 // (sample-wise) or per class (class-wise: row = label).  Every step is a separately rounded fp32
-// operation, as numpy / torch perform them: no fused multiply-add.
+// operation, as numpy / torch perform them: no fused multiply-add.  prescaled: pert already holds
+// clamp(255 * perturbation, -255, 255) rounded to fp32 (the product of a float64 perturbation file is formed in
+// float64 and rounded once, dataset.py:1235 then :534/:550).
 // ------------------------------------------------------------------------------------------------
 __global__ void poison_u8_kernel(const uint8_t* src, const float* pert, const int64_t* labels, const uint8_t* mask,
-                                 uint8_t* dst, long N, int HW) {
+                                 uint8_t* dst, long N, int HW, int prescaled) {
     const long total = N * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long n = i / HW;
@@ -402,7 +404,8 @@ __global__ void poison_u8_kernel(const uint8_t* src, const float* pert, const in
         const long row = labels ? (long)labels[n] : n;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float noise = fminf(fmaxf(__fmul_rn(pert[(row * 3 + c) * HW + px], 255.f), -255.f), 255.f);
+            const float pv = pert[(row * 3 + c) * HW + px];
+            const float noise = prescaled ? pv : fminf(fmaxf(__fmul_rn(pv, 255.f), -255.f), 255.f);
             const float v = fminf(fmaxf(__fadd_rn((float)s[c], noise), 0.f), 255.f);
             d[c] = (uint8_t)(int)v;
         }

@@ -53,14 +53,19 @@ def _upsample(a, size):
     return a[..., :, i0, :] * (1 - w)[:, None] + a[..., :, i1, :] * w[:, None]
 
 
-def synthetic_separable(n=50000, size=32, classes=10, seed=0, template_seed=1234, clutter=0.25, noise=0.05):
+def synthetic_separable(n=50000, size=32, classes=10, seed=0, template_seed=1234, clutter=0.25, noise=0.05, separation=1.0):
     """A class-separable stand-in for CIFAR (no dataset can be fetched here): every class has a fixed smooth colour
     template (shared by train and test sets through ``template_seed``); an image is its class template at a random
     contrast plus a smooth random clutter field and pixel noise.  A ResNet-18 learns it in a few epochs, and a
     class-wise additive pattern of a few grey levels is an easier shortcut than the templates -- which is what makes an
-    unlearnable-example poison work."""
+    unlearnable-example poison work.  ``separation`` < 1 pulls the class templates towards their common mean (1 = as
+    drawn), ``clutter`` scales the class-independent field that lives in the same 4 x 4 colour space: together they
+    set how much of the set a perfect classifier can get right, i.e. how hard the stand-in is."""
     trng = np.random.default_rng(template_seed)
-    templates = _upsample(trng.uniform(0.1, 0.9, (classes, 4, 4, 3)).astype(np.float32), size)
+    t44 = trng.uniform(0.1, 0.9, (classes, 4, 4, 3)).astype(np.float32)
+    if separation != 1.0:
+        t44 = t44.mean(0, keepdims=True) + np.float32(separation) * (t44 - t44.mean(0, keepdims=True))
+    templates = _upsample(t44, size)
     rng = np.random.default_rng(seed)
     y = (np.arange(n) % classes).astype(np.int64)
     out = np.empty((n, size, size, 3), dtype=np.uint8)
@@ -103,7 +108,13 @@ class DeviceLoader:
         ver = getattr(self.dataset, "version", 0)      # bumped by whoever overwrites dataset.data in place
         if self._dev_data is None or self._src is not self.dataset.data or self._ver != ver:
             self._src, self._ver = self.dataset.data, ver
-            self._dev_data = torch.from_numpy(self.dataset.data).to(self.device)
+            # whoever wrote this version of dataset.data may have left its device copy behind (the purification pass
+            # does, after its all-gather): same bytes, no upload
+            dc = getattr(self.dataset, "_device_copy", None)
+            if dc is not None and dc[0] == ver and dc[1].device == self.device and dc[1].shape == self.dataset.data.shape:
+                self._dev_data = dc[1]
+            else:
+                self._dev_data = torch.from_numpy(self.dataset.data).to(self.device)
             self._dev_targets = torch.from_numpy(self.dataset.targets).to(self.device)
         return self._dev_data, self._dev_targets
 
@@ -145,13 +156,19 @@ def poison_dataset(dataset: ArrayDataset, perturbation: torch.Tensor, perturb_ty
     """Apply unlearnable-example noise to a uint8 set the way ``PoisonCIFAR10.__init__`` does
     (dataset.py:1231-1289): ``data = uint8(clip(float32(data) + clamp(255 * perturbation, -255, 255), 0, 255))`` for the
     selected samples, with ``perturbation`` the float tensor of ``perturbation.pt`` ([N,3,H,W] sample-wise or
-    [classes,3,H,W] class-wise, full-image noise).  The arithmetic runs on the device (libdvae_hip, bit-exact against
-    numpy's); ``dataset.data`` is overwritten in place.  Returns the sorted indices of the poisoned samples
+    [classes,3,H,W] class-wise, full-image noise).  The reference forms ``255 * perturbation`` and the clamp in the
+    file's own dtype (dataset.py:1235) and the result becomes float32 when it is written into the float32 image-sized
+    mask (dataset.py:534, :550).  A float32 file goes to the kernel as it is; for any other dtype (the
+    ``perturbation{it}.pt`` files of main_vae_disentangle.py:91-92 are float64) product and clamp are formed in that
+    dtype on the device and rounded to float32 once -- casting the file to float32 first can move a pixel by one grey
+    level.  The arithmetic runs on the device (libdvae_hip); ``dataset.data`` is overwritten in place.  Returns the sorted indices of the poisoned samples
     (``poison_samples_idx``; with ``poison_rate`` < 1 they are drawn without replacement from a generator seeded with
     ``seed``, not from numpy's global state as the reference does)."""
     from . import _lib as L
     n, H, W, _ = dataset.data.shape
-    pert = perturbation.detach().to(torch.float32)
+    pert = perturbation.detach()
+    if not pert.dtype.is_floating_point:
+        raise ValueError(f"perturbation must be a floating-point tensor, got {pert.dtype}")
     if pert.dim() != 4 or tuple(pert.shape[1:]) != (3, H, W):
         raise ValueError(f"perturbation must be [rows,3,{H},{W}] (full-image noise), got {tuple(pert.shape)}")
     rows = pert.shape[0]
@@ -178,7 +195,10 @@ def poison_dataset(dataset: ArrayDataset, perturbation: torch.Tensor, perturb_ty
         mask[torch.from_numpy(poison_samples_idx).to(dev)] = 1
     labels = torch.from_numpy(dataset.targets).to(dev) if perturb_type == "classwise" else None
     pd = pert.contiguous().to(dev)
-    L.check(L.lib().dvae_poison_u8(L.ptr(d), L.ptr(pd), L.ptr(labels), L.ptr(mask), L.ptr(d), n, H * W, L.stream()))
+    prescaled = int(pd.dtype != torch.float32)
+    if prescaled:
+        pd = pd.mul(255).clamp_(-255, 255).to(torch.float32)
+    L.check(L.lib().dvae_poison_u8(L.ptr(d), L.ptr(pd), L.ptr(labels), L.ptr(mask), L.ptr(d), n, H * W, prescaled, L.stream()))
     dataset.data[...] = d.cpu().numpy()
     dataset.version = getattr(dataset, "version", 0) + 1
     dataset.poison_samples_idx = poison_samples_idx.tolist()

@@ -41,6 +41,102 @@ def init_from_env(backend: str | None = None):
     return world_info()
 
 
+def backend() -> str | None:
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+
+
+_SINGLE_NODE = {}
+
+
+def single_node() -> bool:
+    """True when every rank of the job runs on this host (they can then meet in shared host memory).  Decided once per
+    process group by comparing host names (plus the boot id, so that two containers with one name do not pass)."""
+    rank, world = world_info()
+    if world == 1:
+        return True
+    key = id(dist.group.WORLD)
+    if key not in _SINGLE_NODE:
+        import socket
+        try:
+            boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            boot = ""
+        names = [None] * world
+        dist.all_gather_object(names, (socket.gethostname(), boot, os.path.isdir("/dev/shm")))
+        _SINGLE_NODE[key] = all(x == names[0] for x in names) and names[0][2]
+    return _SINGLE_NODE[key]
+
+
+class SharedHostBuffers:
+    """Named host tensors that every rank of a one-node job maps from the same /dev/shm files: ``bufs[name]`` is the whole
+    tensor on every rank, a write by one rank is visible to all after ``barrier()``.  Rank 0 creates the files (sized, zero
+    pages untouched), the others map them after a barrier; ``detach(name, owner)`` ends the sharing: the owner keeps its
+    mapping as an ordinary tensor, every file is unlinked.  Used by the purification pass so that each rank delivers its
+    own shard of the results without a collective (main_vae_disentangle.py:66-69 writes them from one process)."""
+
+    _count = 0
+
+    def __init__(self, specs: dict):
+        rank, world = world_info()
+        token = [None]
+        if rank == 0:
+            SharedHostBuffers._count += 1
+            token[0] = f"dvae_{os.getpid()}_{SharedHostBuffers._count}"
+        dist.broadcast_object_list(token, src=0)
+        self.paths, self.t = {}, {}
+        for name, (shape, dtype) in specs.items():
+            self.paths[name] = f"/dev/shm/{token[0]}_{name}"
+        if rank == 0:
+            for name, (shape, dtype) in specs.items():
+                self.t[name] = self._map(name, shape, dtype, create=True)
+        dist.barrier()
+        if rank != 0:
+            for name, (shape, dtype) in specs.items():
+                self.t[name] = self._map(name, shape, dtype, create=False)
+        self._unlinked = False
+
+    def _map(self, name, shape, dtype, create):
+        n = 1
+        for k in shape:
+            n *= int(k)
+        nbytes = max(1, n) * torch.empty((), dtype=dtype).element_size()
+        if create:
+            with open(self.paths[name], "wb") as f:
+                f.truncate(nbytes)
+        return torch.from_file(self.paths[name], shared=True, size=max(1, n), dtype=dtype)[:n].view(shape)
+
+    def __getitem__(self, name):
+        return self.t[name]
+
+    def barrier(self):
+        dist.barrier()
+
+    def detach(self, name, owner=0):
+        """End the sharing (collective).  Returns the tensor ``name`` on rank ``owner`` -- still backed by the mapping, which
+        lives as long as the tensor -- and None elsewhere.  Every rank must have taken what it needs from the other
+        buffers before the call."""
+        rank, _ = world_info()
+        if rank == 0 and not self._unlinked:         # every rank mapped the files in __init__: the names can go now
+            for p in self.paths.values():
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+        self._unlinked = True
+        dist.barrier()                               # every rank has taken what it needs; the names are gone
+        keep = self.t[name] if rank == owner else None
+        self.t = {}
+        return keep
+
+    def __del__(self):
+        if not getattr(self, "_unlinked", True) and world_info()[0] == 0:
+            for p in self.paths.values():
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+
+
 def shard_range(n: int, rank: int, world: int):
     """Contiguous index range [lo, hi) of rank: ceil(n / world) images per rank, the tail rank(s) short."""
     per = (n + world - 1) // world

@@ -372,6 +372,12 @@ class DVAEEngine:
             st = self._side = torch.cuda.Stream(device=self.dev)
         return st
 
+    def _comm_stream(self):
+        st = getattr(self, "_comm", None)
+        if st is None:
+            st = self._comm = torch.cuda.Stream(device=self.dev)
+        return st
+
     def _wgrad(self, name, x, dy, b):
         """Weight (and bias) gradient of one conv, issued on the side stream: nothing later in backward reads it, so it
         runs next to the input-gradient chain (short, latency-bound launches) instead of in front of it.  All weight
@@ -384,12 +390,24 @@ class DVAEEngine:
         with torch.cuda.stream(side):
             self._wgrad_now(name, x, dy, b)
 
-    def _reduce_table(self, b):
-        """Job records of the one-launch slab reduction for batch size b (built once per b)."""
-        ent = self._reduce_jobs.get(b)
+    def _early_names(self):
+        """The convs whose weight gradients are complete before the stem's backward starts (the latent convs and both
+        decoders).  Their parameters, with the class embedding, are the tail of the flat bucket from ``early_offset``."""
+        return [n for n in self.specs if n in ("fc", "post_conv") or n.startswith("decoder")]
+
+    @property
+    def early_offset(self):
+        return dict((n, o) for n, _, o, _ in self.layout)["fc_mu.weight"]
+
+    def _reduce_table(self, b, part="all"):
+        """Job records of the one-launch slab reduction for batch size b (built once per b).  ``part``: "all", or
+        "early" / "late" = the two halves of a data-parallel step, whose first half is reduced (and its gradients sent on
+        their way) while the stem's backward still runs."""
+        ent = self._reduce_jobs.get((b, part))
         if ent is None:
             nb = self.lib.dvae_wgrad_reduce_job_bytes()
-            names = list(self.specs)
+            early = self._early_names()
+            names = [n for n in self.specs if part == "all" or (n in early) == (part == "early")]
             host = torch.zeros(len(names) * nb, dtype=torch.uint8)
             widest = 0
             for i, name in enumerate(names):
@@ -400,11 +418,11 @@ class DVAEEngine:
                                                      C.byref(self.desc(name, b)), self.dtype, host.data_ptr() + i * nb,
                                                      C.byref(blocks)))
                 widest = max(widest, blocks.value)
-            ent = self._reduce_jobs[b] = (host.to(self.dev), len(names), widest)
+            ent = self._reduce_jobs[(b, part)] = (host.to(self.dev), len(names), widest)
         return ent
 
-    def _wgrad_reduce_all(self, b):
-        jobs, n, widest = self._reduce_table(b)
+    def _wgrad_reduce_all(self, b, part="all"):
+        jobs, n, widest = self._reduce_table(b, part)
         check(self.lib.dvae_wgrad_reduce_batch(ptr(jobs), n, widest, L.stream()))
 
     def _wgrad_now(self, name, x, dy, b):
@@ -688,9 +706,13 @@ class DVAEEngine:
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def backward(self, d_rec_pre=None, d_p=None, d_mulv_extra=None):
+    def backward(self, d_rec_pre=None, d_p=None, d_mulv_extra=None, allreduce=None):
         """Gradients of every parameter on the path into self.G.  With no arguments the loss
-        gradients come from the fused loss kernels (scal must hold the gate coefficients)."""
+        gradients come from the fused loss kernels (scal must hold the gate coefficients).
+        ``allreduce(tensor)`` (data-parallel steps): the gradient bucket is summed over ranks in two pieces.  The tail of
+        the bucket -- latent convs, decoders, class embedding: two thirds of it -- is complete once the weight gradient
+        of fc_mu|fc_var has run; it is reduced and sent from the side stream while the main stream still walks the
+        stem's backward.  The head follows when backward has joined the side stream."""
         L_ = self._last
         b, S, h = L_["b"], self.S, self.h
         rows_h = b * h * h
@@ -727,6 +749,16 @@ class DVAEEngine:
             d_mulv.add_(d_mulv_extra)
         stem_out = L_["stem_out"]
         self._wgrad("fc", stem_out, d_mulv, b)
+        split = allreduce is not None and self._batch_reduce and self._overlap
+        if split:
+            # everything behind early_offset is final once the side stream gets here (emb_bwd ran on the main stream
+            # before the fc weight gradient was issued, and _wgrad made the side stream wait for that point)
+            side, comm = self._side_stream(), self._comm_stream()
+            with torch.cuda.stream(side):
+                self._wgrad_reduce_all(b, "early")
+            comm.wait_stream(side)                           # a stream of its own: the stem's weight gradients, which
+            with torch.cuda.stream(comm):                    # follow on the side stream, do not queue behind the collective
+                allreduce(self.G[self.early_offset:])
         if cfg.sample_wise and cfg.use_y:
             d_stem = d_ep
             self._dgrad("fc", d_mulv, d_stem, b, accumulate=True)
@@ -747,11 +779,15 @@ class DVAEEngine:
                 side = self._side_stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    self._wgrad_reduce_all(b)
+                    self._wgrad_reduce_all(b, "late" if split else "all")
             else:
                 self._wgrad_reduce_all(b)
         if self._overlap:
             torch.cuda.current_stream().wait_stream(self._side_stream())
+        if allreduce is not None:
+            allreduce(self.G[:self.early_offset] if split else self.G)
+        if split:
+            torch.cuda.current_stream().wait_stream(self._comm_stream())
 
     def _block_out_shape(self, blk):
         sp = self.specs[blk + ".conv1"]
@@ -831,9 +867,7 @@ class DVAEEngine:
         if allreduce is not None:
             allreduce(self.sums)
         self.loss_gate(epoch, kld_target, kld_weight, world)
-        self.backward()
-        if allreduce is not None:
-            allreduce(self.G)
+        self.backward(allreduce=allreduce)
         self.adam_step()
 
     def train_step_graphed(self, x0, y, eps, b, epoch, kld_target, kld_weight, allreduce=None, world=1):

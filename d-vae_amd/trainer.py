@@ -119,7 +119,13 @@ class VAE_Trainer:
             loss = loss + max(loss_p, 0.002)
         loss.backward()
         grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
-        optimizer.step()            # the model notices the in-place update (tensor versions) and re-packs its weights
+        optimizer.step()
+        # The model notices in-place updates through the tensors' version counters, but writes through ``param.data``
+        # (hand-written SGD, EMA swaps, clamps) bump a different counter: after a foreign optimiser's step the packed
+        # weights and the folded BatchNorm are always re-made (one launch).  Code that edits ``p.data`` elsewhere must call
+        # ``model._engine.invalidate()`` itself.
+        if getattr(model, "_engine", None) is not None:
+            model._engine.invalidate()
         self._monitor(images, labels, rec.detach(), perturbation.detach(), model_c)
         vals = dict(loss=loss.item(), loss_rec=loss_rec.item(), loss_rec_p=loss_rec_p.item(), loss_p=loss_p.item(),
                     kld_loss=kld_loss.item())
@@ -222,7 +228,33 @@ class VAE_Trainer:
         return out
 
 
-_STAGE = {}
+_STAGE = {}          # kind -> (key, pinned buffers): ONE entry per kind, replaced (and its pinned memory freed) when the key changes
+_COPY_STREAM = {}    # device index -> the side stream the drains copy on
+
+
+def _staging(kind, key, make):
+    """Pinned staging buffers of one kind ("chunk" | "drain").  A pass keeps re-using them; a different (batch, image
+    size, dtype) drops the old ones first, so the page-locked footprint is that of the current pass only:
+    3 x batch x (3 S S x 8 + 3 S S) bytes for the drain (85 MB at 1024 images of 32 x 32, 340 MB at 64 x 64)."""
+    ent = _STAGE.get(kind)
+    if ent is None or ent[0] != key:
+        _STAGE.pop(kind, None)
+        ent = _STAGE[kind] = (key, make())
+    return ent[1]
+
+
+def release_staging():
+    """Free every pinned staging buffer (and side stream) kept by purify_dataset's host drains."""
+    _STAGE.clear()
+    _COPY_STREAM.clear()
+
+
+def _copy_stream():
+    dev = torch.cuda.current_device()
+    st = _COPY_STREAM.get(dev)
+    if st is None:
+        st = _COPY_STREAM[dev] = torch.cuda.Stream()
+    return st
 
 
 def _to_host_chunked(src, dst, chunk_rows=4096):
@@ -235,10 +267,8 @@ def _to_host_chunked(src, dst, chunk_rows=4096):
     if n == 0:
         return dst
     row = tuple(src.shape[1:])
-    key = (row, dst.dtype, chunk_rows)
-    if key not in _STAGE:
-        _STAGE[key] = [torch.empty((chunk_rows,) + row, dtype=dst.dtype, pin_memory=True) for _ in range(2)]
-    stage = _STAGE[key]
+    stage = _staging("chunk:" + str(dst.dtype), (row, dst.dtype, chunk_rows),
+                     lambda: [torch.empty((chunk_rows,) + row, dtype=dst.dtype, pin_memory=True) for _ in range(2)])
     pending = []
     for k, lo in enumerate(range(0, n, chunk_rows)):
         hi = min(n, lo + chunk_rows)
@@ -266,12 +296,10 @@ class _HostDrain:
 
     def __init__(self, dst_u8, dst_f64, rows, row_u8, row_f64):
         self.dst = (dst_u8, dst_f64)
-        key = ("drain", rows, row_u8, row_f64)
-        if key not in _STAGE:
-            _STAGE[key] = [(torch.empty((rows,) + row_u8, dtype=torch.uint8, pin_memory=True),
-                            torch.empty((rows,) + row_f64, dtype=torch.float64, pin_memory=True)) for _ in range(self.DEPTH)]
-        self.stage = _STAGE[key]
-        self.stream = torch.cuda.Stream()
+        self.stage = _staging("drain", (rows, row_u8, row_f64), lambda: [
+            (torch.empty((rows,) + row_u8, dtype=torch.uint8, pin_memory=True),
+             torch.empty((rows,) + row_f64, dtype=torch.float64, pin_memory=True)) for _ in range(self.DEPTH)])
+        self.stream = _copy_stream()
         self.pending = []
         self.k = 0
 
@@ -306,8 +334,10 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 
     """The epoch-0 branch of ``Trainer.train`` (main_vae_disentangle.py:59-69) for a whole dataset:
     overwrites ``dataset.data`` in place with the purified uint8 images and returns the recorded
     perturbations as a float64 tensor [N,3,H,W] (on rank 0; the other ranks, which do not save it, get None).
-    Images are sharded over ranks by contiguous index range; the uint8 shards are all-gathered at the end (every
-    rank trains the next stage on the full purified set), the perturbations are gathered to rank 0 only.  The
+    Images are sharded over ranks by contiguous index range.  On one node every rank drains its own shard (uint8 images
+    and float64 perturbations) into shared host memory while it computes its later batches; afterwards every rank holds
+    the full purified set (it trains the next stage on it) and rank 0 the perturbations.  Over several nodes the uint8
+    shards are all-gathered and the perturbations gathered to rank 0.  The
     reparameterisation noise is keyed by global image index, so the result does not depend on the world size or the
     batch size.  BatchNorm running statistics are taken from rank 0 (``DataParallel`` keeps replica 0's,
     main_vae_disentangle.py:426-428), so every shard is purified by the same function.
@@ -335,12 +365,21 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 
     if timings is not None:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-    # One rank: finished batches drain to the host (dataset.data in place, main_vae_disentangle.py:67, and the float64
-    # perturbations) under the batches that follow.  Several ranks: gather first, then one chunked copy.
-    drain = None
-    if world == 1 and dev.type == "cuda" and overlap_tail:
+    # Finished batches drain to the host under the batches that follow (uint8 images; float64 perturbations converted on
+    # the device), every rank its own shard.  One rank: straight into dataset.data (main_vae_disentangle.py:67) and the
+    # result tensor.  Several ranks on one node: into two buffers in shared host memory, so that no rank moves another
+    # rank's perturbations and no collective carries them; after a barrier every rank copies the other shards' uint8 rows
+    # into its own dataset.data and rank 0 owns the float64 buffer.  Ranks spread over nodes: gather, then one chunked copy.
+    drain = shared = None
+    cuda = dev.type == "cuda"
+    if world == 1 and cuda and overlap_tail:
         res = torch.empty(n, 3, S, S, dtype=torch.float64)
         drain = _HostDrain(torch.from_numpy(dataset.data), res, eng.B, tuple(data.shape[1:]), (3, S, S))
+    elif world > 1 and overlap_tail and D.single_node():
+        shared = D.SharedHostBuffers({"u8": ((n,) + tuple(dataset.data.shape[1:]), torch.uint8),
+                                      "noise": ((n, 3, S, S), torch.float64)})
+        if cuda:
+            drain = _HostDrain(shared["u8"][lo:hi], shared["noise"][lo:hi], eng.B, tuple(data.shape[1:]), (3, S, S))
     for first in range(0, hi - lo, eng.B):
         b = min(eng.B, hi - lo - first)
         eng.purify_batch(data, out, noise, labels, first, b, stage, global_first=lo + first)
@@ -349,7 +388,22 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 
     if timings is not None:
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-    if drain is not None:
+    if shared is not None:
+        # RCCL: the uint8 shards are all-gathered on the device as well (19 MB per rank at 8 GPUs, asynchronous to the host)
+        # and handed to the device-resident loaders of the next stage, which then skip the 153 MB re-upload
+        if cuda and D.backend() == "nccl":
+            dataset._device_copy = (getattr(dataset, "version", 0) + 1, D.all_gather_shards(out, n))
+        if drain is not None:
+            drain.finish()
+        else:
+            shared["u8"][lo:hi].copy_(out)
+            shared["noise"][lo:hi].copy_(noise)
+        shared.barrier()                                     # every shard is in place
+        if timings is not None:
+            t3 = time.perf_counter()
+        torch.from_numpy(dataset.data).copy_(shared["u8"])
+        res = shared.detach("noise", owner=0)                # rank 0 keeps the mapping (the others get None); files unlinked
+    elif drain is not None:
         if timings is not None:
             t3 = t2
         drain.finish()

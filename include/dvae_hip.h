@@ -115,6 +115,9 @@ int dvae_conv_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, int ac
 size_t dvae_conv_wgrad_workspace_bytes(const dvae_conv_desc* d);   /* the workspace must be 16-byte aligned */
 int dvae_conv_wgrad(const void* x, const void* dy, float* dw_ref, float* db_ref /* or NULL */,
                     void* workspace, size_t workspace_bytes, const dvae_conv_desc* d, int dtype, void* stream);
+/* 1 when this (desc, dtype) is served by the 256 x 128-tile weight-gradient kernel (bf16, K >= 512, >= 128 dense
+ * channels, >= 100 000 pixel rows), 0 otherwise: lets a test assert which kernel a launch exercised. */
+int dvae_conv_wgrad_uses_big_tiles(const dvae_conv_desc* d, int dtype);
 /* The same gradient in two steps, so that a backward pass reduces the slabs of ALL its convs in one launch (autograd
  * of the convs in resnet.py:2139-2150, :2008-2050; main_vae_disentangle.py:209).  dvae_conv_wgrad_partial leaves the
  * per-chunk slabs (and, with want_bias, the bias partials) in a workspace that belongs to this conv until the batch
@@ -254,12 +257,17 @@ int dvae_purify_quant(const void* a, const float* b, int a_is_f32, void* v_out /
 
 /* ---- unlearnable-example ingress (PoisonCIFAR10, dataset.py:1235, :1287-1289) ------------------
  * dst = uint8(clip(float(src) + clamp(255 * perturbation, -255, 255), 0, 255)) on uint8 NHWC images, every step one
- * rounded fp32 operation as numpy performs it (bit-exact against the reference's arithmetic).  perturbation is fp32
- * NCHW [rows][3][HW]: row = image index (sample-wise, labels == NULL) or row = labels[image] (class-wise).
+ * rounded fp32 operation as numpy performs it.  perturbation is fp32 NCHW [rows][3][HW]: row = image index
+ * (sample-wise, labels == NULL) or row = labels[image] (class-wise).  The reference scales and clamps the tensor in
+ * the dtype of the perturbation file (dataset.py:1235) and the result is rounded to float32 when it is placed into the
+ * float32 image-sized mask (dataset.py:534, :550): with prescaled == 0 the kernel forms the fp32 product itself
+ * (float32 files); for a float64 file the caller forms clamp(255 * p, -255, 255) in float64, rounds it to fp32 once
+ * and passes that with prescaled == 1.
  * mask (uint8 [N], or NULL = all) selects the poisoned images (poison_rate < 1); the others are copied.
  * dst may alias src. */
 int dvae_poison_u8(const uint8_t* src_u8_nhwc, const float* perturbation_nchw, const int64_t* labels /* or NULL */,
-                   const uint8_t* mask /* or NULL */, uint8_t* dst_u8_nhwc, int64_t N, int HW, void* stream);
+                   const uint8_t* mask /* or NULL */, uint8_t* dst_u8_nhwc, int64_t N, int HW, int prescaled,
+                   void* stream);
 
 /* ---- clip_grad_norm_ + Adam (main_vae_disentangle.py:210-211, resnet18DVAE.yaml:21-23) -------
  * hyper (device, fp32[8]): lr, beta1, beta2, eps, max_norm, grad_scale, steps_done, unused;

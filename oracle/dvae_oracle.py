@@ -407,13 +407,16 @@ def purify(p, cfg, data_u8, labels, eps_fn, stage: int, batch: int = 128):
 # --------------------------------------------------------------------------------------------
 def poison_u8(data_u8: np.ndarray, perturbation: torch.Tensor, targets=None, poison_samples_idx=None) -> np.ndarray:
     """PoisonCIFAR10.__init__ (dataset.py:1235, :1241, :1287-1289) for full-image noise: the perturbation tensor is
-    scaled by 255, clamped to [-255, 255] and permuted to HWC; each selected image becomes
-    uint8(clip(float32(image) + noise, 0, 255)).  ``targets`` given = class-wise (row = label), else sample-wise."""
-    pt = perturbation.to(torch.float32).mul(255).clamp_(-255, 255).permute(0, 2, 3, 1).numpy()
+    scaled by 255 and clamped to [-255, 255] in its own dtype (:1235) and permuted to HWC; patch_noise_extend_to_img
+    writes the image's noise into a float32 mask (:534, :550; for full-image noise the mask is the noise, rounded to
+    float32); each selected image becomes uint8(clip(float32(image) + mask, 0, 255)).  ``targets`` given =
+    class-wise (row = label), else sample-wise."""
+    pt = perturbation.clone().mul(255).clamp_(-255, 255).permute(0, 2, 3, 1).numpy()
     out = data_u8.astype(np.float32)
     idx = range(len(out)) if poison_samples_idx is None else poison_samples_idx
     for i in idx:
-        noise = pt[int(targets[i])] if targets is not None else pt[i]
+        noise = np.zeros(out[i].shape, np.float32)
+        noise[...] = pt[int(targets[i])] if targets is not None else pt[i]
         out[i] = out[i] + noise
         out[i] = np.clip(out[i], a_min=0, a_max=255)
     return out.astype(np.uint8)

@@ -33,6 +33,7 @@ from oracle import dvae_oracle as O  # noqa: E402  (recipe + input seeds only)
 
 REF = "/root/reference/configs/models/resnet.py"
 SUB = 37   # stride of the flattened subsample stored for the large maps
+SUB224 = 499   # ... of the 224x224 fixture's maps (49 x the pixels)
 
 
 def load_reference():
@@ -84,9 +85,9 @@ def ref_forward(net, x, y, eps):
     return stem_out, rec, mu, log_var, z, perturbation
 
 
-def summarize(t):
+def summarize(t, sub=SUB):
     f = t.detach().reshape(-1)
-    return {"sub": f[::SUB].numpy().copy(), "mean": np.float64(f.double().mean()),
+    return {"sub": f[::sub].numpy().copy(), "mean": np.float64(f.double().mean()),
             "absmax": np.float64(f.abs().max()), "l2": np.float64(f.double().norm())}
 
 
@@ -284,6 +285,61 @@ def gen_purify64(ref):
     print("g4_purify64.npz", len(out), "arrays")
 
 
+def gen_purify224(ref):
+    """ImageNet-mini shape (224x224, 100 classes).  The snapshot's own configuration for it (stem_end_block 15,
+    configs/imagenet-mini/resnet18DVAE.yaml:11) does not build a working module (channel mismatch, resnet.py:2105-2107);
+    the module the reference does run at any resolution is stem_end_block 7 with the plain class embedding, and that is
+    what is pinned here: the purification loop of main_vae_disentangle.py:59-69 over N=3 images in batches of 2 (ragged
+    tail), both stages, plus one train-mode forward of 2 images (BatchNorm batch statistics over 100 352 pixels).  The
+    uint8 results are stored whole; the float maps as a strided subsample with their norms."""
+    out = {}
+    cfg = O.DVAEConfig(image_size=224, spatial_emb=False, num_classes=100)
+    N, B = 3, 2
+    rng = np.random.default_rng(13)
+    data = rng.integers(0, 256, size=(N, 224, 224, 3), dtype=np.uint8)
+    labels = (np.arange(N) * 41 + 7) % 100
+    g = torch.Generator().manual_seed(299)
+    eps_all = torch.randn(2, N, cfg.latent_dim, 112, 112, generator=g)
+    out["data"] = data
+    out["labels"] = labels
+    for stage in (0, 1):
+        net, _ = build_ref_model(ref, cfg)
+        net.eval()
+        res = np.empty_like(data)
+        noise = np.zeros((N, 3, 224, 224), dtype=np.float32)
+        idx = 0
+        for lo in range(0, N, B):
+            hi = min(N, lo + B)
+            images = torch.from_numpy(data[lo:hi]).permute(0, 3, 1, 2).float().div(255)   # ToTensor
+            lab = torch.as_tensor(labels[lo:hi], dtype=torch.long)
+            with torch.no_grad():
+                _, rec, mu, lv, z, perturbation = ref_forward(net, images, lab, eps_all[0, lo:hi])
+                images = (images - perturbation).clamp(0, 1).detach()
+                if stage > 0:
+                    _, rec, mu, lv, z, perturbation = ref_forward(net, images, lab, eps_all[1, lo:hi])
+                    images = rec.clamp(0, 1).detach()
+            for k in range(images.shape[0]):
+                res[idx] = np.clip(255 * images[k].cpu().permute(1, 2, 0).numpy(), a_min=0, a_max=255).astype(np.uint8)
+                noise[idx] = perturbation[k].detach().cpu().numpy()
+                idx += 1
+        out[f"stage{stage}.u8"] = res
+        flat(summarize(torch.from_numpy(noise), SUB224), f"stage{stage}.noise", out)
+    # one train-mode forward (batch statistics, running-statistics update)
+    x = torch.from_numpy(data[:2]).permute(0, 3, 1, 2).float().div(255)
+    lab = torch.as_tensor(labels[:2], dtype=torch.long)
+    net, _ = build_ref_model(ref, cfg)
+    net.train()
+    with torch.no_grad():
+        stem_out, rec, mu, lv, z, pert = ref_forward(net, x, lab, eps_all[0, :2])
+    for nm, t in (("stem_out", stem_out), ("mu", mu), ("log_var", lv), ("z", z), ("rec", rec), ("perturbation", pert)):
+        flat(summarize(t, SUB224), "train." + nm, out)
+    sd = net.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.shortcut.1.running_mean", "layer2.0.bn2.running_var"):
+        out["train.stat." + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g4_purify224.npz"), **out)
+    print("g4_purify224.npz", len(out), "arrays")
+
+
 def gen_dp_step(ref):
     """One train step the way torch.nn.DataParallel over 2 devices runs it (main_vae_disentangle.py:426-428): the
     8-image batch goes through the reference module in two contiguous chunks of 4 (train-mode BatchNorm sees one chunk
@@ -371,7 +427,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = load_reference()
     gens = {"forward": gen_forward, "loss_grads": gen_loss_grads, "trajectory": gen_trajectory, "purify": gen_purify,
-            "purify64": gen_purify64, "dp_step": gen_dp_step, "quant_kat": lambda r: gen_quant_kat(),
+            "purify64": gen_purify64, "purify224": gen_purify224, "dp_step": gen_dp_step, "quant_kat": lambda r: gen_quant_kat(),
             "state_dict_keys": gen_state_dict_keys, "resnet18_keys": gen_resnet18_keys}
     for name in (sys.argv[1:] or list(gens)):       # no arguments: regenerate everything
         gens[name](ref)

@@ -64,6 +64,21 @@ def _worker(rank, world, port, n, tmp):
     torch.nn.functional.cross_entropy(net(xs), ys).backward()
     for a, q in zip(got_g, net.parameters()):
         assert torch.allclose(a, q.grad, atol=1e-6)
+    # one node: every rank delivers its shard through shared host memory, no collective carries the data
+    assert D.single_node() and D.backend() == "gloo"
+    sh = D.SharedHostBuffers({"u8": ((n, 8, 8, 3), torch.uint8), "noise": ((n,), torch.float64)})
+    paths = list(sh.paths.values())
+    assert all(os.path.exists(q) for q in paths)
+    sh["u8"][lo:hi].copy_(local_u8)
+    sh["noise"][lo:hi].copy_(local_noise)
+    sh.barrier()
+    assert torch.equal(sh["u8"], 255 - full)                                   # the other rank's rows are visible
+    mine_u8 = sh["u8"].clone()
+    kept = sh.detach("noise", owner=0)
+    assert (kept is None) == (rank != 0) and not any(os.path.exists(q) for q in paths)
+    if rank == 0:
+        assert kept.dtype == torch.float64 and torch.equal(kept, full.float().mean(dim=(1, 2, 3)).double())
+    assert torch.equal(mine_u8, 255 - full)
     sums = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
     D.allreduce_sum_(sums)
     assert torch.equal(sums, torch.tensor([1.0, 2.0, 3.0, 4.0]) * sum(range(1, world + 1)))

@@ -279,6 +279,25 @@ def test_poison_ingress_is_bit_exact_against_numpy_restatement():
     assert np.array_equal(ds2.data[untouched], data[untouched]) and not np.array_equal(ds2.data[idx2], data[idx2])
     with pytest.raises(ValueError):
         DD.poison_dataset(ds, pert[:10], "samplewise")
+    # float64 files (what main_vae_disentangle.py:91-92 writes): 255 * p and the clamp in double, one rounding
+    p64 = pert.double() * (1 - 2.0 ** -26)
+    ds3 = DD.ArrayDataset(data.copy(), targets)
+    DD.poison_dataset(ds3, p64, "samplewise")
+    assert np.array_equal(ds3.data, O.poison_u8(data, p64))
+
+
+def test_poison_ingress_matches_hand_derived_reference_answers():
+    """The device ingress against the known answers of tests/poison_kat.py, which follow dataset.py:1235, :534-550,
+    :1287-1289 by hand (the reference's dataset module cannot be imported here: torchvision is absent), for float32
+    and float64 perturbation files: bit-exact."""
+    import poison_kat
+    for dt, (x, p, want) in poison_kat.as_arrays().items():
+        ds = DD.ArrayDataset(x.copy(), np.zeros(1, dtype=np.int64))
+        DD.poison_dataset(ds, p, "samplewise")
+        assert np.array_equal(ds.data, want), dt
+        dsc = DD.ArrayDataset(x.copy(), np.zeros(1, dtype=np.int64))
+        DD.poison_dataset(dsc, p, "classwise")                   # one class: the same noise by label
+        assert np.array_equal(dsc.data, want), dt
 
 
 # ------------------------------------------------------------------------------------------------

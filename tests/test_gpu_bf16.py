@@ -295,6 +295,11 @@ BACKWARD = [
     (64, 128, 3, 2, 1, False, 32),      # slab weight gradient; image-resident input-gradient (9 slabs)
     (128, 64, 4, 2, 1, True, 16),
     (128, 128, 3, 1, 1, False, 16),
+    # 512 images of 16 x 16 maps = 131 072 pixel rows: past the 100 000 rows from which the wide slabs go to the
+    # large-tile weight-gradient kernel (256 x 128 tiles, both bias-partial modes, the 1152 = 4.5 x 256 K tail)
+    (64, 128, 3, 2, 1, False, 32, 512),
+    (128, 64, 4, 2, 1, True, 16, 512),
+    (128, 128, 3, 1, 1, False, 16, 512),
 ]
 
 
@@ -304,9 +309,9 @@ def test_backward_kernels_at_train_batch(cfg):
     384 here: three such batches), where their workgroups loop over many tiles: the input gradient of an image does
     not depend on the batch (bit-exact against 3-image launches), and the weight / bias gradient is linear in the
     batch (the 384-image launch against the sum of three 128-image launches, fp32 summation order apart: 1e-4)."""
-    cin, cout, k, stride, pad, tr, hin = cfg
+    cin, cout, k, stride, pad, tr, hin = cfg[:7]
     lib = L.lib()
-    B, b = 384, 3
+    B, b = (cfg[7] if len(cfg) > 7 else 384), 3
     g = torch.Generator().manual_seed(29 + cin + cout + k)
     sp = ConvSpec("t", cin, cout, k, stride, pad, tr, hin, True)
     w = torch.randn(sp.wshape, generator=g) / (cin * k * k) ** 0.5
@@ -340,7 +345,10 @@ def test_backward_kernels_at_train_batch(cfg):
     for lo in (0, 190, B - b):
         assert torch.equal(big[lo:lo + b, ..., :cin], dgrad(lo, b)[..., :cin]), f"input gradient of images {lo}.. differs"
     dw, db = wgrad(0, B)
-    parts = [wgrad(lo, 128) for lo in (0, 128, 256)]
+    if B > 384:
+        d = L.ConvDesc(B, hin, hin, cin, cout, k, k, stride, pad, int(tr))
+        assert lib.dvae_conv_wgrad_uses_big_tiles(C.byref(d), L.BF16) == 1
+    parts = [wgrad(lo, 128) for lo in range(0, B, 128)]
     assert rel_err(dw.cpu(), sum(p_[0] for p_ in parts).cpu()) < 1e-4
     assert rel_err(db.cpu(), sum(p_[1] for p_ in parts).cpu()) < 1e-4
 

@@ -241,6 +241,18 @@ def test_oracle_poison_arithmetic_known_answers():
     assert (q2[0] == 11).all() and (q2[1] == 7).all()
 
 
+def test_oracle_poison_matches_hand_derived_reference_answers():
+    """The oracle's ingress restatement against known answers worked out by hand from dataset.py:1235, :534-550,
+    :1287-1289 (tests/poison_kat.py): float32 and float64 perturbation files, including the pixel where rounding a
+    float64 file to float32 before the multiplication lands one grey level off."""
+    from oracle import dvae_oracle as O
+    import poison_kat
+    for dt, (x, p, want) in poison_kat.as_arrays().items():
+        assert np.array_equal(O.poison_u8(x, p), want), dt
+    x, p64, want = poison_kat.as_arrays()["float64"]
+    assert not np.array_equal(O.poison_u8(x, p64.float()), want)     # the float32-first shortcut is visibly wrong
+
+
 def test_synthetic_separable_set_is_deterministic_and_shares_templates():
     a = DD.synthetic_separable(n=40, seed=1)
     b = DD.synthetic_separable(n=40, seed=1)

@@ -147,6 +147,48 @@ def test_purification_64x64_matches_reference(golden_dir, stage):
     assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
 
 
+SUB224 = 499
+
+
+def inputs_224(g):
+    """Inputs of the 224x224 fixture (tests/golden/make_golden.py::gen_purify224): images and labels from the file, the
+    reparameterisation noise of both passes from its seed."""
+    cfg = O.DVAEConfig(image_size=224, spatial_emb=False, num_classes=100)
+    data, labels = g["data"], g["labels"]
+    eps_all = torch.randn(2, data.shape[0], cfg.latent_dim, 112, 112, generator=torch.Generator().manual_seed(299))
+    return cfg, data, labels, eps_all
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_purification_224x224_matches_reference(golden_dir, stage):
+    """ImageNet-mini shape (224x224, 100 classes) on the module the reference can run at that size (stem_end_block 7, plain
+    class embedding): N = 3 in ragged batches of 2.  The snapshot's stem_end_block-15 variant does not build and stays
+    unpinned."""
+    g = np.load(os.path.join(golden_dir, "g4_purify224.npz"))
+    cfg, data, labels, eps_all = inputs_224(g)
+    p = O.recipe_params(cfg)
+    u8, noise = O.purify(p, cfg, data, labels, lambda ps, lo, hi: eps_all[ps, lo:hi], stage, batch=2)
+    close(noise.reshape(-1)[::SUB224], g[f"stage{stage}.noise.sub"], 5e-5)
+    close(float(np.linalg.norm(noise.reshape(-1))), g[f"stage{stage}.noise.l2"], 5e-5)
+    diff = np.abs(u8.astype(np.int32) - g[f"stage{stage}.u8"].astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
+
+
+def test_train_forward_224x224_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_purify224.npz"))
+    cfg, data, labels, eps_all = inputs_224(g)
+    p = O.recipe_params(cfg)
+    x = torch.from_numpy(data[:2]).permute(0, 3, 1, 2).float().div(255)
+    stats = {}
+    with torch.no_grad():
+        out = O.forward(p, cfg, x, torch.as_tensor(labels[:2], dtype=torch.long), eps_all[0, :2], True, stats)
+    for nm in ("stem_out", "mu", "log_var", "z", "rec", "perturbation"):
+        close(out[nm].reshape(-1)[::SUB224].numpy(), g[f"train.{nm}.sub"])
+        close(float(out[nm].double().norm()), g[f"train.{nm}.l2"])
+    for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.shortcut.1.running_mean", "layer2.0.bn2.running_var"):
+        close(stats[k].numpy(), g[f"train.stat.{k}"])
+
+
 def test_data_parallel_step_matches_reference(golden_dir):
     """DataParallel arithmetic (per-replica BatchNorm statistics, whole-batch loss, summed gradients, replica 0's
     running statistics kept) against the fixture made from two parameter-sharing instances of the reference module."""
