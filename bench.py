@@ -42,15 +42,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--purify-batch", type=int, default=1024)
+    ap.add_argument("--purify-batch", type=int, default=None,
+                    help="images per GPU per purification step (default 1024; 128 at 224x224: the same order of pixels per launch)")
     ap.add_argument("--train-batch", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="activation / MFMA input type (accumulation, statistics, losses, optimiser are fp32 either way)")
-    ap.add_argument("--images", type=int, default=50000)
+    ap.add_argument("--images", type=int, default=None,
+                    help="size of the synthetic set (default 50 000; 8 192 at 224x224, the ImageNet-mini configuration)")
     ap.add_argument("--stage", type=int, default=1, choices=[0, 1],
                     help="purification stage: 1 (two forwards, the headline) or 0 (one forward, x - p)")
-    ap.add_argument("--image-size", type=int, default=32, choices=[32, 64],
-                    help="32: CIFAR-10 shape (the headline workload); 64: Tiny-ImageNet shape (200 classes, plain class embedding)")
+    ap.add_argument("--image-size", type=int, default=32, choices=[32, 64, 224],
+                    help="32: CIFAR-10 shape (the headline workload); 64: Tiny-ImageNet shape (200 classes, plain class embedding); "
+                         "224: ImageNet-mini shape (100 classes, plain class embedding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (clean per-kernel timings)")
@@ -60,7 +63,12 @@ def parse():
     ap.add_argument("--no-purify", action="store_true", help="profiling aid: skip the purification region")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32 (reference precision) leg of a bf16 run")
     ap.add_argument("--no-pass", action="store_true", help="skip the whole-dataset pass through purify_dataset")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.purify_batch is None:
+        a.purify_batch = 128 if a.image_size == 224 else 1024
+    if a.images is None:
+        a.images = 8192 if a.image_size == 224 else 50000
+    return a
 
 
 def respawn_under_torchrun(n):
@@ -92,7 +100,11 @@ def max_over_ranks(t, world):
 
 
 def model_kwargs(S):
-    return {} if S == 32 else dict(image_size=S, spatial_emb=False, num_classes=200)
+    return {} if S == 32 else dict(image_size=S, spatial_emb=False, num_classes=200 if S == 64 else 100)
+
+
+def shape_name(S):
+    return {32: "CIFAR-10 shape", 64: "64x64 Tiny-ImageNet shape", 224: "224x224 ImageNet-mini shape"}[S]
 
 
 def cpu_baseline(n_images, stage=1, S=32):
@@ -345,11 +357,11 @@ def main():
             dist.destroy_process_group()
         return
     res = {
-        "metric": "purified images/sec (node) + VAE train imgs/sec, " + ("CIFAR-10 shape" if S == 32 else f"{S}x{S} Tiny-ImageNet shape"),
+        "metric": "purified images/sec (node) + VAE train imgs/sec, " + shape_name(S),
         "value": purify_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": purify_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": f"synthetic uint8 {S}x{S}x3 images resident in HBM, random-init weights",
-        "config": {"workload": ("CIFAR-10 shape 32x32x3" if S == 32 else f"Tiny-ImageNet shape {S}x{S}x3, 200 classes") +
+        "config": {"workload": shape_name(S) + f" {S}x{S}x3, {cfg.num_classes} classes" +
                                ", ResNet18DVAE(seb=7, latent=256), " +
                                ("stage-1 purification (2 eval forwards + clamp + uint8 quantise)" if a.stage == 1 else
                                 "stage-0 purification (1 eval forward + clamp + uint8 quantise)") +

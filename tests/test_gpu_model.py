@@ -236,6 +236,56 @@ def test_purification_64x64_vs_golden(golden_dir, stage):
     assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
 
 
+SUB224 = 499
+
+
+def _inputs_224(g):
+    data, labels = g["data"], g["labels"]
+    eps_all = torch.randn(2, data.shape[0], 256, 112, 112, generator=torch.Generator().manual_seed(299))
+    return data, labels, eps_all
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_purification_224x224_vs_golden(golden_dir, stage):
+    """ImageNet-mini shape (224x224, 100 classes) on the module the reference runs at that size (stem_end_block 7, plain
+    class embedding; the snapshot's stem_end_block-15 variant does not build and stays unpinned): purify_batch against
+    the fixture made with the reference's module, N = 3 in ragged batches of 2.  224 = 7 x 32 rows and columns: tile
+    grids that are not powers of two.  Same bar as at 32x32; the perturbations are held as a strided subsample + norm."""
+    g = np.load(os.path.join(golden_dir, "g4_purify224.npz"))
+    ocfg, eng, p = make_engine(dict(image_size=224, spatial_emb=False, num_classes=100), 2)
+    data, labels, eps_all = _inputs_224(g)
+    N = data.shape[0]
+    d_dev = torch.from_numpy(data).cuda()
+    out = torch.zeros_like(d_dev)
+    noise = torch.zeros(N, 3, 224, 224, device="cuda")
+    lab = torch.from_numpy(labels).cuda().long()
+    for lo in range(0, N, 2):
+        b = min(2, N - lo)
+        eng.purify_batch(d_dev, out, noise, lab, lo, b, stage, eps_nchw=(eps_all[0, lo:lo + b].cuda(), eps_all[1, lo:lo + b].cuda()))
+    nz = noise.cpu()
+    assert rel_err(nz.reshape(-1)[::SUB224], g[f"stage{stage}.noise.sub"]) < 1e-4
+    ref = float(g[f"stage{stage}.noise.l2"])
+    assert abs(float(nz.double().norm()) - ref) <= 1e-4 * ref
+    diff = np.abs(out.cpu().numpy().astype(np.int32) - g[f"stage{stage}.u8"].astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 0.005
+
+
+def test_train_forward_224x224_vs_golden(golden_dir):
+    """One train-mode forward of 2 images at 224x224 (BatchNorm batch statistics over 100 352 pixels per channel, running
+    statistics update) against the reference-generated fixture."""
+    g = np.load(os.path.join(golden_dir, "g4_purify224.npz"))
+    ocfg, eng, p = make_engine(dict(image_size=224, spatial_emb=False, num_classes=100), 2)
+    data, labels, eps_all = _inputs_224(g)
+    x = torch.from_numpy(data[:2]).permute(0, 3, 1, 2).float().div(255)
+    out = run_forward(eng, x, torch.as_tensor(labels[:2], dtype=torch.long), eps_all[0, :2], True)
+    for nm in ("stem_out", "mu", "log_var", "z", "rec", "perturbation"):
+        assert rel_err(out[nm].reshape(-1)[::SUB224], g[f"train.{nm}.sub"]) < 5e-5, nm
+        ref = float(g[f"train.{nm}.l2"])
+        assert abs(float(out[nm].double().norm()) - ref) <= 5e-5 * ref, nm
+    for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.shortcut.1.running_mean", "layer2.0.bn2.running_var"):
+        assert rel_err(eng.buffers[k].cpu(), g[f"train.stat.{k}"]) < 5e-5, k
+
+
 def test_in_kernel_philox_equals_materialised_noise():
     """forward() with a PhiloxEps draws exactly the numbers dvae_philox_normal writes for the same key."""
     ocfg, eng, p = make_engine({}, 4)
