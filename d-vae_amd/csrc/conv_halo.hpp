@@ -26,6 +26,32 @@
 
 namespace dvae {
 
+// Tile grid of one image: ntx tiles per tile row, tpi tiles per image; tile index = (image * nty + ty) * ntx + tx.
+// Dividing by the two counts is a shift where the count is a power of two (32x32 and 64x64 images) and otherwise a
+// multiply-high by ceil(2^32 / d), which is exact for dividends below 2^32 / d (make_tile_grid checks the largest one).
+struct TileGrid {
+    int ntx, tpi;
+    int lx, ltpi;            // log2 of ntx / tpi, or -1
+    unsigned inv_ntx, inv_tpi;
+    __device__ __forceinline__ int div_ntx(int n) const { return lx >= 0 ? n >> lx : (int)__umulhi((unsigned)n, inv_ntx); }
+    __device__ __forceinline__ int div_tpi(int n) const { return ltpi >= 0 ? n >> ltpi : (int)__umulhi((unsigned)n, inv_tpi); }
+    // tile -> image and tile coordinates inside it
+    __device__ __forceinline__ void split(int tile, int& b, int& ty, int& tx) const {
+        b = div_tpi(tile);
+        const int rem = tile - b * tpi;
+        ty = div_ntx(rem);
+        tx = rem - ty * ntx;
+    }
+};
+// false if the grid's divisions would not be exact for `max_dividend`
+static bool make_tile_grid(int ntx, int nty, long max_dividend, TileGrid& g) {
+    g.ntx = ntx; g.tpi = ntx * nty;
+    g.lx = ilog2_exact(ntx); g.ltpi = ilog2_exact(g.tpi);
+    g.inv_ntx = ntx > 1 ? (unsigned)(((1ull << 32) + ntx - 1) / ntx) : 0u;
+    g.inv_tpi = g.tpi > 1 ? (unsigned)(((1ull << 32) + g.tpi - 1) / g.tpi) : 0u;
+    return max_dividend >= 0 && max_dividend * g.tpi < (1ll << 32) && max_dividend < 0x7fffffffL;
+}
+
 struct HaloArgs {
     const void* in;
     const void* wp;
@@ -37,7 +63,7 @@ struct HaloArgs {
     int in_relu;
     int B, H, W, N, NS, Ktot;
     int relu, add_after_relu, out_f32;
-    int lx, ly;              // log2 of the tile counts per image row / column (both powers of two)
+    TileGrid g;              // tiles of an image
     signed char dy[16], dx[16];
     float* stats;            // optional [B][tiles per image * 8][2][NS]: sum and sum of squares of the stored bf16 output
                              // over each wave's 32 pixels (for the normalisation that follows the conv), or null
@@ -84,8 +110,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     const int n0 = blockIdx.y * NT;
     const bf16* in = reinterpret_cast<const bf16*>(a.in);
     const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
-    const int ntiles = a.B << (a.lx + a.ly);
-    const int mx = (1 << a.lx) - 1, my = (1 << a.ly) - 1;
+    const int ntiles = a.B * a.g.tpi;
 
     // ---- weights (every tap) and the epilogue's per-channel scale/shift -> LDS, once -----------------
     for (int v = tid; v < 9 * NT * VPP; v += 512) {
@@ -117,7 +142,9 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     unsigned inimg = 0;                                   // bit k: hreg[k] is a pixel inside the image
     f32x4 isc[2], ish[2];                                 // input normalisation of this thread's 8 channels
     auto tile_origin = [&](int tile, int& y0, int& x0, int& b) {
-        x0 = (tile & mx) * TW; y0 = ((tile >> a.lx) & my) * TH; b = tile >> (a.lx + a.ly);
+        int ty, tx;
+        a.g.split(tile, b, ty, tx);
+        x0 = tx * TW; y0 = ty * TH;
     };
     auto load_halo_vec = [&](int tile, int k) {           // k-th vector of `tile`'s halo -> hreg[k]
         int y0, x0, b;
@@ -203,7 +230,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 32, 64);
         if (sp == 0 && chunk_live) {
-            float* dst = a.stats + (((long)(tile >> (a.lx + a.ly)) * 8 + wave) * 2) * a.NS + n0 + sc8 * 8;
+            float* dst = a.stats + (((long)a.g.div_tpi(tile) * 8 + wave) * 2) * a.NS + n0 + sc8 * 8;
             f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
             f32x4 q0 = {v[8], v[9], v[10], v[11]}, q1 = {v[12], v[13], v[14], v[15]};
             *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
@@ -245,12 +272,14 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     // kernel -- and an image's chunks do not depend on the batch it is in.  The normalising consumer follows the same
     // order so that an image stays on the XCD (blockIdx.x mod 8) whose L2 its producer wrote it through.
     constexpr bool IMO = IN_SS || STATS;
-    const int ltpi = a.lx + a.ly, tpi_m = (1 << ltpi) - 1;
+    const int tpi = a.g.tpi;
     auto tile_at = [&](int i) -> int {
         if (!IMO) return blockIdx.x + i * (int)gridDim.x;
-        return ((blockIdx.x + (i >> ltpi) * (int)gridDim.x) << ltpi) + (i & tpi_m);
+        const int j = a.g.div_tpi(i);
+        return (blockIdx.x + j * (int)gridDim.x) * tpi + (i - j * tpi);
     };
-    const int nit = IMO ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) << ltpi
+    auto in_image = [&](int i) -> int { return i - a.g.div_tpi(i) * tpi; };   // position of iteration i's tile in its image (IMO)
+    const int nit = IMO ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * tpi
                         : (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     int tile = tile_at(0);
     if (nit > 0) {
@@ -265,10 +294,11 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
         HALO_STAMP(1);
         __syncthreads();                                   // halo (and, first time, weights) visible
         HALO_STAMP(2);
-        const int next = tile_at(it + 1), prev = tile_at(it - 1);
+        const int next = tile_at(it + 1), prev = tile_at(it > 0 ? it - 1 : 0);
         const bool drain = staged && it > 0, fetch_add = staged && a.add != nullptr, fetch_next = it + 1 < nit;
         // statistics: the drained tile (it - 1) opens / closes an image
-        const bool st_open = ((it - 1) & tpi_m) == 0, st_close = ((it - 1) & tpi_m) == tpi_m;
+        const int st_pos = STATS ? in_image(it > 0 ? it - 1 : 0) : 0;
+        const bool st_open = st_pos == 0, st_close = st_pos == tpi - 1;
         u32x4 dreg;
         // q-th global access of this tile (compile-time q): drain reads/stores, add fetches, halo fetches
         auto mem_op = [&](int q) {
@@ -409,7 +439,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     // ---- the last tile's output is still parked in the patch ----
     if (staged && it > 0) {
         const int last = tile_at(it - 1);
-        if (((it - 1) & tpi_m) == 0) {                     // one tile per image: the last tile opens its image too
+        if (STATS && in_image(it - 1) == 0) {              // one tile per image: the last tile opens its image too
 #pragma unroll
             for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
         }
@@ -448,7 +478,9 @@ static HaloGeom halo_geom(const GemmPlan& P) {
     if (P.CgS != 32 && P.CgS != 64) return none;
     const int TW = (P.Wout % 32 == 0) ? 32 : ((P.Wout % 16 == 0) ? 16 : 0);
     if (!TW || P.Hout % (256 / TW)) return none;
-    if (ilog2_exact(P.Wout / TW) < 0 || ilog2_exact(P.Hout / (256 / TW)) < 0) return none;
+    TileGrid tg;
+    // (the largest dividend is the index of a tile one grid stride past the last image)
+    if (!make_tile_grid(P.Wout / TW, P.Hout / (256 / TW), ((long)P.B + 1024) * (P.Wout / TW) * (P.Hout / (256 / TW)), tg)) return none;
     const int NT = (P.Npad % 64 == 0) ? 64 : 32;
     if (halo_lds_bytes_of(P.CgS, NT, TW) > HALO_LDS_MAX) return none;
     const HaloGeom g = {TW, NT};
@@ -477,9 +509,9 @@ static bool try_launch_halo_bf16(const GemmPlan& P, const void* in, const void* 
     a.in_ss = in_ss; a.in_relu = in_relu; a.stamps = stamps; a.stats = stats;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = out_f32 ? act_channels(P.N) : P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.out_f32 = out_f32;
-    a.lx = ilog2_exact(P.Wout / TW); a.ly = ilog2_exact(P.Hout / (256 / TW));
+    make_tile_grid(P.Wout / TW, P.Hout / (256 / TW), 0, a.g);
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
-    const int ntiles = P.B << (a.lx + a.ly);
+    const int ntiles = P.B * a.g.tpi;
     // persistent workgroups, tiles strided over the grid: one per CU where the LDS footprint allows no more, two for the
     // small shapes (32 -> 32 channels: 66 KB), whose tiles are mostly serial latency that a second workgroup hides
     const int per_cu = 2 * halo_lds_bytes_of(P.CgS, NT, TW) <= HALO_LDS_MAX ? 2 : 1;

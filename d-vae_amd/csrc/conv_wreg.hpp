@@ -221,18 +221,23 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     const int lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * NT;
     const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
-    const int mx = (1 << a.lx) - 1, my = (1 << a.ly) - 1, ltpi = a.lx + a.ly, tpi_m = (1 << ltpi) - 1;
-    const int ntiles = a.B << ltpi;
+    const int tpi = a.g.tpi;
+    const int ntiles = a.B * tpi;
     // Tile order: with at least one image per workgroup a workgroup walks whole images (image j of workgroup g is
     // g + j * gridDim.x, tiles in order), so the two halo rows neighbouring tiles share are re-read from the cache level
     // that just served them; otherwise tiles are strided over the grid.
     const bool imo = a.B >= (int)gridDim.x;
-    const int tsh = imo ? ltpi : 0, tmsk = imo ? tpi_m : 0;           // (one branch-free form for both orders)
-    auto tile_at = [&](int i) -> int { return (((int)blockIdx.x + (i >> tsh) * (int)gridDim.x) << tsh) + (i & tmsk); };
-    const int nit = imo ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) << ltpi
+    const int tgrp = imo ? tpi : 1;                                   // (one branch-free form for both orders)
+    auto tile_at = [&](int i) -> int {
+        const int j = imo ? a.g.div_tpi(i) : i;
+        return ((int)blockIdx.x + j * (int)gridDim.x) * tgrp + (i - j * tgrp);
+    };
+    const int nit = imo ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * tpi
                         : (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_origin = [&](int tile, int& y0, int& x0, int& b) {
-        x0 = (tile & mx) * TW; y0 = ((tile >> a.lx) & my) * TH; b = tile >> ltpi;
+        int ty, tx;
+        a.g.split(tile, b, ty, tx);
+        x0 = tx * TW; y0 = ty * TH;
     };
 
     // ---- this thread's share of a halo tile: vectors v = tid + 256 k, i.e. halo pixel p0 + k * PSTEP, channel chunk cv.
@@ -574,8 +579,7 @@ static constexpr int wreg_lds_bytes_of(int CIN, int NT) {
 // true if the plan (a halo-kernel plan with 32-wide tiles) runs on the weights-in-registers kernel
 static bool wreg_applicable(const GemmPlan& P) {
     const HaloGeom hg = halo_geom(P);
-    if (hg.TW != 32 || P.Hout % 8 || P.CgS != 64) return false;
-    return ilog2_exact(P.Hout / 8) >= 0;
+    return hg.TW == 32 && P.Hout % 8 == 0 && P.CgS == 64;
 }
 
 static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
@@ -596,9 +600,9 @@ static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* 
     a.add = res ? res : (accumulate ? out : nullptr); a.add_after_relu = 0;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.out_f32 = 0; a.stamps = stamps;
-    a.lx = ilog2_exact(P.Wout / 32); a.ly = ilog2_exact(P.Hout / 8);
+    make_tile_grid(P.Wout / 32, P.Hout / 8, 0, a.g);
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
-    const int ntiles = P.B << (a.lx + a.ly);
+    const int ntiles = P.B * a.g.tpi;
     const int gx = ntiles < 256 ? ntiles : 256;            // persistent: one workgroup per CU
     dim3 grid(gx, P.Npad / NT), block(256);
 #define WREG_CASE(C, N, A)                                                                               \

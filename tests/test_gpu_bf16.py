@@ -41,6 +41,13 @@ CONVS = [
     (64, 64, 3, 1, 1, False, 64, False),      # 64x64 images: all-tap weight gradient with two tiles per row
     (256, 128, 1, 1, 0, False, 16, True),     # post_conv: weights-resident 1x1 kernel
     (128, 128, 3, 1, 1, False, 16, False),    # layer2's second conv: image-resident kernel, two blocks of 64 channels
+    # tile grids that are not powers of two (224 = 7 x 32 columns, 28 x 8 rows; 96 = 3 x 32, 12 x 8): the persistent
+    # kernels split a tile index by multiply-high instead of shifts
+    (64, 64, 3, 1, 1, False, 96, False),      # weights-in-registers conv both ways, all-tap weight gradient
+    (64, 32, 3, 1, 1, True, 96, True),
+    (32, 3, 3, 1, 1, True, 96, True),         # LDS-weights kernel, 32 stored input channels
+    (3, 64, 3, 1, 1, False, 96, False),       # first conv
+    (64, 64, 3, 1, 1, False, 224, False),
 ]
 
 
@@ -242,6 +249,10 @@ PERSISTENT = [
     (256, 128, 1, 1, 0, False, 16, "plain"),    # weights-resident 1x1
     (128, 64, 4, 2, 1, True, 16, "plain"),      # image-resident transposed conv
     (128, 128, 3, 1, 1, False, 16, "res"),      # image-resident 3x3 with residual
+    (64, 64, 3, 1, 1, False, 96, "res", 300),   # 36 tiles per image (not a power of two): whole-image walk, 300 images
+    (64, 64, 3, 1, 1, False, 96, "plain", 60),  # ... fewer images than workgroups: tiles strided over the grid
+    (32, 3, 3, 1, 1, True, 96, "f32", 120),
+    (3, 64, 3, 1, 1, False, 96, "plain", 120),
 ]
 
 
@@ -252,9 +263,9 @@ def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
     tests give every workgroup at most one tile, so this one runs 800 images (3 to 13 tiles per workgroup) and
     requires every image's output to equal, bit for bit, what a 3-image launch computes for it: a conv has no
     cross-image term (resnet.py:26-31, :2139-2167), so any difference is a tile-loop hazard."""
-    cin, cout, k, stride, pad, tr, hin, mode = cfg
+    cin, cout, k, stride, pad, tr, hin, mode = cfg[:8]
     lib = L.lib()
-    B, b = 800, 3
+    B, b = (cfg[8] if len(cfg) > 8 else 800), 3
     g = torch.Generator().manual_seed(17 + cin + cout)
     sp = ConvSpec("t", cin, cout, k, stride, pad, tr, hin, True)
     w = torch.randn(sp.wshape, generator=g) / (cin * k * k) ** 0.5
@@ -282,7 +293,7 @@ def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
 
     big = run(0, B)
     assert torch.isfinite(big.float()).all()
-    for lo in (0, 398, B - b):
+    for lo in (0, B // 2 - 2, B - b):
         small = run(lo, b)
         assert torch.equal(big[lo:lo + b, ..., :cout], small[..., :cout]), f"images {lo}..{lo + b - 1} differ"
 
@@ -300,6 +311,7 @@ BACKWARD = [
     (64, 128, 3, 2, 1, False, 32, 512),
     (128, 64, 4, 2, 1, True, 16, 512),
     (128, 128, 3, 1, 1, False, 16, 512),
+    (64, 64, 3, 1, 1, False, 96, 256),  # 36 tiles per image: not a power of two
 ]
 
 
@@ -419,7 +431,7 @@ def test_fused_encoder_head_bf16(B, Ld):
 
 
 @pytest.mark.parametrize("cin,cout,hin,tr,B", [(64, 64, 32, True, 5), (64, 32, 32, True, 5), (32, 64, 64, False, 5),
-                                               (64, 32, 32, True, 600)])
+                                               (64, 32, 32, True, 600), (64, 64, 96, True, 5), (64, 32, 96, True, 300)])
 def test_conv_output_statistics_bf16(cin, cout, hin, tr, B):
     """InstanceNorm2d statistics (resnet.py:2030-2046) gathered by the producing conv's store against the
     stand-alone statistics kernel on the stored tensor: same values up to fp32 summation order.  With 600 images a
@@ -461,13 +473,13 @@ def test_conv_output_statistics_bf16(cin, cout, hin, tr, B):
     assert rel_err(out["fused"][0][:, :cout].cpu(), y.mean(dim=(2, 3))) < 2e-5
 
 
-@pytest.mark.parametrize("cin,cout,B,f32out", [(64, 32, 3, False), (64, 32, 600, False), (32, 3, 700, True)])
-def test_conv_input_normalisation_prologue_bf16(cin, cout, B, f32out):
+@pytest.mark.parametrize("cin,cout,B,f32out,hin", [(64, 32, 3, False, 32), (64, 32, 600, False, 32), (32, 3, 700, True, 32),
+                                                   (64, 32, 300, False, 96), (32, 3, 300, True, 96)])
+def test_conv_input_normalisation_prologue_bf16(cin, cout, B, f32out, hin):
     """The decoders' convs consume ReLU(InstanceNorm2d(x)) (resnet.py:2030-2046): the per-image scale / shift and the
     ReLU applied while the conv stages its input, against the same conv on a tensor normalised beforehand.  600 / 700
     images: more than the launch has workgroups, so a workgroup changes image (and scale / shift) inside its loop."""
     lib = L.lib()
-    hin = 32
     g = torch.Generator().manual_seed(11 + cout + B)
     sp = ConvSpec("t", cin, cout, 3, 1, 1, True, hin, True)
     w = torch.randn(sp.wshape, generator=g) / (cin * 9) ** 0.5
