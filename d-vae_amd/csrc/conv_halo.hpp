@@ -113,17 +113,29 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(const HaloArgs a) {
     const int ntiles = a.B * a.g.tpi;
 
     // ---- weights (every tap) and the epilogue's per-channel scale/shift -> LDS, once -----------------
-    for (int v = tid; v < 9 * NT * VPP; v += 512) {
-        const int t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, cv = rem % VPP;
-        *reinterpret_cast<u32x4*>(wlds + t * WTAP + n * WR + ((cv ^ ((n >> WSH) & (VPP - 1))) * 16)) =
-            *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + cv * 8);
-    }
+    // (every load issued before the first LDS write: a load-store loop waits out one memory latency per round)
+    float ssl_sc = 0.f, ssl_sh = 0.f;
     if (tid < NT) {
         const int n = n0 + tid;
         const bool live = n < a.N;
-        ssl[tid] = (live && a.scale) ? a.scale[n] : (live ? 1.f : 0.f);
-        ssl[NT + tid] = (live && a.shift) ? a.shift[n] : 0.f;
+        ssl_sc = (live && a.scale) ? a.scale[n] : (live ? 1.f : 0.f);
+        ssl_sh = (live && a.shift) ? a.shift[n] : 0.f;
     }
+    {
+        constexpr int WV = (9 * NT * VPP + 511) / 512;
+        u32x4 wtmp[WV];
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + 512 * i, t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, cv = rem % VPP;
+            if (v < 9 * NT * VPP) wtmp[i] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + cv * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + 512 * i, t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, cv = rem % VPP;
+            if (v < 9 * NT * VPP) *reinterpret_cast<u32x4*>(wlds + t * WTAP + n * WR + ((cv ^ ((n >> WSH) & (VPP - 1))) * 16)) = wtmp[i];
+        }
+    }
+    if (tid < NT) { ssl[tid] = ssl_sc; ssl[NT + tid] = ssl_sh; }
     int toff[9];                                          // LDS byte offset of each tap relative to the centre pixel
 #pragma unroll
     for (int t = 0; t < 9; ++t) toff[t] = ((int)a.dy[t] * HWD + (int)a.dx[t]) * RS;

@@ -46,9 +46,18 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     constexpr int XV = 128 * PT_VPP / 512;               // vectors per thread of a tile (and of the weights)
 
-    for (int v = tid; v < 128 * PT_VPP; v += 512) {
-        const int n = v / PT_VPP, cv = v % PT_VPP;
-        *reinterpret_cast<u32x4*>(wlds + n * PT_RS + cv * 16) = *reinterpret_cast<const u32x4*>(a.wp + (long)n * a.Ktot + cv * 8);
+    {   // (every load issued before the first LDS write: a load-store loop waits out one memory latency per round)
+        u32x4 wtmp[XV];
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + 512 * i, n = v / PT_VPP, cv = v % PT_VPP;
+            wtmp[i] = *reinterpret_cast<const u32x4*>(a.wp + (long)n * a.Ktot + cv * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + 512 * i, n = v / PT_VPP, cv = v % PT_VPP;
+            *reinterpret_cast<u32x4*>(wlds + n * PT_RS + cv * 16) = wtmp[i];
+        }
     }
     if (tid < PT_N) {
         ssl[tid] = a.scale ? a.scale[tid] : 1.f;

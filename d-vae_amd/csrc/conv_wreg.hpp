@@ -42,8 +42,15 @@ namespace dvae {
         if (a.stamps && tid == 0 && it < 64)                                                             \
             a.stamps[((long)blockIdx.x * 64 + it) * 8 + (i)] = __builtin_readcyclecounter();             \
     } while (0)
+// ... and the constant 100 MHz clock (the same on every CU) at four points of the workgroup's life, into tile slot 63:
+// entry, weights in registers, tile loop done, exit.
+#define WREG_RSTAMP(i)                                                                                   \
+    do {                                                                                                 \
+        if (a.stamps && tid == 0) a.stamps[((long)blockIdx.x * 64 + 63) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define WREG_STAMP(i) do { } while (0)
+#define WREG_RSTAMP(i) do { } while (0)
 #endif
 
 // D = A * B (zero C) / D += A * B with the A fragment in the accumulator file or in VGPRs
@@ -59,6 +66,28 @@ __device__ __forceinline__ void mfma_first_v(f32x16& acc, const u32x4& w, const 
 __device__ __forceinline__ void mfma_acc_v(f32x16& acc, const u32x4& w, const u32x4& x) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
 }
+
+#ifdef WREG_X16_TIMING
+// Timing-only build: every 32x32x16 MFMA is issued as two 16x16x32 MFMAs on quarters of the same accumulator (results
+// are wrong; same FLOPs, registers and dependency distances).
+typedef f32x4 wacc_t[4];
+__device__ __forceinline__ void mfma16_first_a(f32x4& acc, const u32x4& w, const u32x4& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(x));
+}
+__device__ __forceinline__ void mfma16_acc_a(f32x4& acc, const u32x4& w, const u32x4& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+}
+__device__ __forceinline__ void mfma16_first_v(f32x4& acc, const u32x4& w, const u32x4& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(x));
+}
+__device__ __forceinline__ void mfma16_acc_v(f32x4& acc, const u32x4& w, const u32x4& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+}
+#define WACC(acc, j, i) acc[j][(i) >> 2][(i) & 3]
+#else
+typedef f32x16 wacc_t;
+#define WACC(acc, j, i) acc[j][i]
+#endif
 
 // ---- the side-operation schedule of one tile ----------------------------------------------------------------------
 // A tile is 2 blocks x G gaps (a gap = the issue slot in front of one MFMA).  An MFMA executes for 32 cycles and holds the
@@ -217,6 +246,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     float* ssl = reinterpret_cast<float*>(smem + 2 * HALO_BYTES);          // scale[NT], shift[NT]
 
     const int tid = threadIdx.x;
+    WREG_RSTAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: it enters buffer-descriptor offsets
     const int lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * NT;
@@ -310,25 +340,40 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
         *reinterpret_cast<u32x4*>(at + buf * HALO_BYTES) = hreg[k];
     };
 
-    int tile = tile_at(0);
-    if (nit > 0) {
-        halo_tile(tile);
-#pragma unroll
-        for (int k = 0; k < HV; ++k) load_halo_vec(k);
-    }
-
     // ---- weights: global -> LDS images (coalesced) -> this wave's A-operand fragments, once ------------------------
-    for (int v = tid; v < 9 * NT * VPP; v += 256) {
-        const int t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, c = rem % VPP;
-        *reinterpret_cast<u32x4*>(smem + t * WTAP + n * WR + ((c ^ ((n >> WSH) & (VPP - 1))) * 16)) =
-            *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + c * 8);
-    }
+    // Every load of the image is issued before the first LDS write (a load-store loop waits out one memory latency per
+    // round: 18 rounds were 7 of the launch's 75 us), and ahead of the first tile's halo, which nothing needs before the
+    // fragments are in registers (loads return in order).
+    constexpr int WV = 9 * NT * VPP / 256;
+    static_assert(9 * NT * VPP % 256 == 0, "the weight image is a whole number of vectors per thread");
+    float ssl_sc = 0.f, ssl_sh = 0.f;                      // epilogue scale / shift of channel n0 + tid (tid < NT)
     if (tid < NT) {
         const int n = n0 + tid;
         const bool live = n < a.N;
-        ssl[tid] = (live && a.scale) ? a.scale[n] : (live ? 1.f : 0.f);
-        ssl[NT + tid] = (live && a.shift) ? a.shift[n] : 0.f;
+        ssl_sc = (live && a.scale) ? a.scale[n] : (live ? 1.f : 0.f);
+        ssl_sh = (live && a.shift) ? a.shift[n] : 0.f;
     }
+    {
+        u32x4 wtmp[WV];
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + 256 * i, t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, c = rem % VPP;
+            wtmp[i] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + n) * a.Ktot + t * CIN + c * 8);
+        }
+        int tile0 = tile_at(0);
+        if (nit > 0) {
+            halo_tile(tile0);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) load_halo_vec(k);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + 256 * i, t = v / (NT * VPP), rem = v % (NT * VPP), n = rem / VPP, c = rem % VPP;
+            *reinterpret_cast<u32x4*>(smem + t * WTAP + n * WR + ((c ^ ((n >> WSH) & (VPP - 1))) * 16)) = wtmp[i];
+        }
+    }
+    int tile = tile_at(0);
+    if (tid < NT) { ssl[tid] = ssl_sc; ssl[NT + tid] = ssl_sh; }
     __syncthreads();
     int woff[KS];                                          // this lane's swizzled chunk of weight row r, per 16-channel slab
 #pragma unroll
@@ -345,6 +390,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
                 if (t < TR) wreg[t][sl][j] = w; else wvr[t >= TR ? t - TR : 0][sl][j] = w;
             }
     __syncthreads();                                       // every wave has its fragments: the staging image is dead
+    WREG_RSTAMP(1);
     if (nit > 0) {
 #pragma unroll
         for (int k = 0; k < HV; ++k) store_halo_vec(0, k);
@@ -400,10 +446,10 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
         const bf16x2_t o = __builtin_convertvector(f, bf16x2_t);      // (bit casts take named objects, never a vector element)
         return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, o), relu_lo));
     };
-    auto epi_a = [&](const f32x16 (&acc)[TN], int e) {
+    auto epi_a = [&](const wacc_t (&acc)[TN], int e) {
         const int j = e / 4, g = e % 4, b = e % EBUF;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) esh[b][k] = acc[j][4 * g + k] * esc[b][k] + esh[b][k];
+        for (int k = 0; k < 4; ++k) esh[b][k] = WACC(acc, j, 4 * g + k) * esc[b][k] + esh[b][k];
         asm volatile("" : "+v"(esh[b]));                   // computed HERE: the optimiser would sink it to its use
     };
     auto epi_r = [&](int e) {
@@ -454,11 +500,11 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     static_assert(SCH.first_ea[0] >= 4 && SCH.first_ea[1] >= 4, "an accumulator set is read too soon after its last MFMA");
     static_assert(SCH.over == 0, "a side operation has no place in the schedule");
 
-    f32x16 acc0[TN], acc1[TN];
+    wacc_t acc0[TN], acc1[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { acc0[j][e] = 0.f; acc1[j][e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { WACC(acc0, j, e) = 0.f; WACC(acc1, j, e) = 0.f; }
 
     // loop-carried tile state: the tile being computed, the one whose halo is being fetched, and the offsets they need
     int it = 0;
@@ -539,6 +585,22 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
                     }
 #endif
                     // ---- the MFMA of this gap ----
+#ifdef WREG_X16_TIMING
+                    {
+                        wacc_t& acc = u == 0 ? acc0[j] : acc1[j];
+                        const int q0 = (2 * st) & 3, q1 = (2 * st + 1) & 3;
+                        if (t < TR) {
+                            if (st < 2) { mfma16_first_a(acc[q0], wreg[t < TR ? t : 0][sl][j], pv[s % (PF + 1)]);
+                                          mfma16_first_a(acc[q1], wreg[t < TR ? t : 0][sl][j], pv[s % (PF + 1)]); }
+                            else { mfma16_acc_a(acc[q0], wreg[t < TR ? t : 0][sl][j], pv[s % (PF + 1)]);
+                                   mfma16_acc_a(acc[q1], wreg[t < TR ? t : 0][sl][j], pv[s % (PF + 1)]); }
+                        } else {
+                            mfma16_acc_v(acc[q0], wvr[t >= TR ? t - TR : 0][sl][j], pv[s % (PF + 1)]);
+                            mfma16_acc_v(acc[q1], wvr[t >= TR ? t - TR : 0][sl][j], pv[s % (PF + 1)]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
                     f32x16& acc = u == 0 ? acc0[j] : acc1[j];
                     if (t < TR) {
                         if (st == 0) mfma_first_a(acc, wreg[t < TR ? t : 0][sl][j], pv[s % (PF + 1)]);
@@ -548,6 +610,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
                         else mfma_acc_v(acc, wvr[t >= TR ? t - TR : 0][sl][j], pv[s % (PF + 1)]);
                     }
                     __builtin_amdgcn_sched_barrier(0);     // keep everything where it was placed
+#endif
                 }
             }
         }
@@ -559,6 +622,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
         tile = next; next = nx_next; hbad = nx_hbad; horg = (unsigned)(nx_pix * CIN * 2);
         pix_next = nx_pix;
     }
+    WREG_RSTAMP(2);
     // ---- block 1 of the last tile is still in its accumulators (its residual rows are parked already) ----
     if (it > 0) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMA's result -> the VALU reads below
@@ -568,6 +632,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) { drain_load(i); drain_store(out_prev1, lane_off, i); }
     }
+    WREG_RSTAMP(3);
 }
 
 static constexpr int wreg_lds_taps(int CIN, int NT) { return (CIN == 64 && NT == 64) ? 1 : 0; }

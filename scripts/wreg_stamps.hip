@@ -57,6 +57,27 @@ int main(int argc, char** argv) {
     const int lastt = (tiles_per_wg < 64 ? tiles_per_wg : 64) - 1;
     printf("  wg0: first tile %llu cycles, tile-loop total %llu cycles over %d tiles\n", s0[6] - s0[0],
            hs[((size_t)0 * 64 + lastt) * 8 + 6] - s0[0], lastt + 1);
+    // life of the workgroups on the constant 100 MHz clock (tile slot 63), relative to the earliest entry
+    if (tiles_per_wg < 63) {
+        unsigned long long t0 = ~0ull;
+        for (int g = 0; g < 256; ++g) { const unsigned long long v = hs[((size_t)g * 64 + 63) * 8]; if (v && v < t0) t0 = v; }
+        double mn[4] = {1e30, 1e30, 1e30, 1e30}, mx[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0};
+        for (int g = 0; g < 256; ++g)
+            for (int k = 0; k < 4; ++k) {
+                const double us = (double)(hs[((size_t)g * 64 + 63) * 8 + k] - t0) * 0.01;
+                if (us < mn[k]) mn[k] = us;
+                if (us > mx[k]) mx[k] = us;
+                av[k] += us / 256;
+            }
+        const char* rn[4] = {"entry", "weights in registers", "tile loop done", "exit"};
+        for (int k = 0; k < 4; ++k) printf("  %-22s min %7.2f  mean %7.2f  max %7.2f us after the first entry\n", rn[k], mn[k], av[k], mx[k]);
+        // per XCD (workgroup g runs on XCD g % 8): when each finishes
+        for (int x = 0; x < 8; ++x) {
+            double a = 0, m = 0;
+            for (int g = x; g < 256; g += 8) { const double us = (double)(hs[((size_t)g * 64 + 63) * 8 + 3] - t0) * 0.01; a += us / 32; if (us > m) m = us; }
+            printf("  XCD %d: exit mean %7.2f max %7.2f us\n", x, a, m);
+        }
+    }
     // gaps between a tile's end and the next tile's start
     double gap = 0; long gc = 0;
     for (int g = 0; g < 256; ++g)
