@@ -224,6 +224,23 @@ def dataset_pass(a, world, rank, dtype_name, S, cfg):
     for k, v in tm.items():
         out[k] = max_over_ranks(v, world)
     out["kernel_only_images_per_sec"] = a.images / out["kernels_s"]
+    if world > 1:
+        # strong scaling of the pass: the same set through ONE rank of this job (the others wait at the barrier), then
+        # efficiency = t(1 rank) / (N * t(N ranks))
+        from dvae_amd import dist as D
+        solo_s = 0.0
+        if rank == 0:
+            ds1 = DD.synthetic_cifar(n=a.images, size=S, classes=cfg.num_classes, seed=0)
+            with D.solo():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                purify_dataset(m, ds1, a.stage, batch=a.purify_batch, seed=0)
+                torch.cuda.synchronize()
+                solo_s = time.perf_counter() - t0
+        barrier(world)
+        solo_s = max_over_ranks(solo_s, world)
+        out["one_rank_wall_s"] = solo_s
+        out["efficiency_vs_1gpu"] = solo_s / (world * wall)
     return out
 
 
@@ -373,8 +390,18 @@ def main():
         "train_tflops": (2.0 * TRAIN_MACS * px * train_ips / 1e12) if train_ips else None,
         "roofline": probe_roofline(a.dtype, probe_ms, Bp, px, S),
     }
+    # the whole timed regions against the dense MFMA peak of their arithmetic (every launch, small ones and gaps included)
+    peak = PEAK_TFLOPS[a.dtype] * world
+    res["step_roofline"] = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                            "purify": {"achieved": res["purify_tflops"], "frac": res["purify_tflops"] / peak},
+                            "train": ({"achieved": res["train_tflops"], "frac": res["train_tflops"] / peak}
+                                      if train_ips else None)}
     if f32_leg is not None:
         res["f32"] = f32_leg
+        res["value_f32"] = f32_leg["value"]               # the reference's own precision, same run
+        res["step_roofline"]["purify_f32"] = {"achieved": 2.0 * (1 + a.stage) * FWD_MACS * px * f32_leg["value"] / 1e12,
+                                              "frac": 2.0 * (1 + a.stage) * FWD_MACS * px * f32_leg["value"] / 1e12 /
+                                              (PEAK_TFLOPS["f32"] * world), "peak": PEAK_TFLOPS["f32"] * world}
     if pass_obj is not None:
         res["pass"] = pass_obj
     if not a.no_cpu_baseline and world == 1:

@@ -11,10 +11,15 @@ Reference lines mirrored (same names, arguments and file layouts):
     train                      /root/reference/main_vae_disentangle.py:323-371
     optimiser / scheduler      /root/reference/configs/cifar10/resnet18.yaml:14-23  (SGD 0.1 / 5e-4 / 0.9, cosine)
 
-This stage is not the accelerated D-VAE path: the classifier runs on stock torch modules.  What is done the MI355X way is
-the data side: the purified set stays resident in HBM as uint8, batches are gathered and augmented on the device
-(``trainer.random_crop_flip``), the confusion matrix is a device ``bincount`` instead of a per-sample host loop, and with
-more than one process gradients are averaged through one flat bucket per step (``DataParallelSGD``).
+On the GPU the convolutional trunk (conv1 .. layer4: every conv, BatchNorm, residual add and ReLU, forward and backward)
+runs on libdvae_hip through ``trunk.ResNetTrunkEngine`` -- the same kernels as the D-VAE's stem plus the layer3 / layer4
+shapes -- in fp32 or with bf16 activations (``act_dtype``; parameters, gradients, BatchNorm statistics and the optimiser
+stay fp32).  Pooling, the linear layer, the loss and SGD are stock torch ops.  There is no stock-torch route for device
+tensors: without the built library a forward on the GPU raises.  CPU tensors run the plain torch modules (the reference's
+own arithmetic; it is what the tests hold the device path to).  The data side is device-resident too: the purified set
+stays in HBM as uint8, batches are gathered and augmented on the device (``trainer.random_crop_flip``), the confusion
+matrix is a device ``bincount``, and with more than one process gradients are averaged through one flat bucket per step
+(``DataParallelSGD``).
 """
 from __future__ import annotations
 
@@ -30,10 +35,44 @@ from .model import _ResBlock
 from .trainer import AverageMeter, log_display
 
 
-class ResNet(nn.Module):
-    """CIFAR ResNet with BasicBlocks: 3x3 stem conv, four stages, global average pool, linear head."""
+class _TrunkFunction(torch.autograd.Function):
+    """conv1 .. layer4 as one autograd node: forward runs the engine, backward receives the gradient of layer4's output
+    and leaves the trunk's parameter gradients in the engine's bucket (``param.grad`` are views of it)."""
 
-    def __init__(self, num_blocks=(2, 2, 2, 2), num_classes=10):
+    @staticmethod
+    def forward(ctx, model, x, anchor):
+        eng = model._engine_for(x)
+        out = eng.forward_trunk(x.detach(), model.training)
+        if model.training:
+            torch._foreach_add_(model._nbt_list, 1)
+            eng.fold_valid = False                        # the kernels advanced the running statistics in place
+        ctx.model, ctx.eng = model, eng
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        eng, model = ctx.eng, ctx.model
+        params = eng.param
+        mine = [n for n in eng.names if params[n].grad is not None and params[n].grad.data_ptr() == eng.grad[n].data_ptr()]
+        saved = {n: eng.grad[n].clone() for n in mine}    # gradients kept from an earlier backward: accumulate
+        eng.backward_trunk(d_out)
+        for n in eng.names:
+            p = params[n]
+            if n in saved:
+                eng.grad[n].add_(saved[n])
+            elif p.grad is None:
+                p.grad = eng.grad[n]
+            else:
+                p.grad.add_(eng.grad[n])
+        return None, None, torch.zeros_like(model._anchor)
+
+
+class ResNet(nn.Module):
+    """CIFAR ResNet with BasicBlocks: 3x3 stem conv, four stages, global average pool, linear head.
+    ``act_dtype`` ("f32" | "bf16", not in the reference, which is fp32): arithmetic of the device trunk; the environment
+    variable DVAE_ACT_DTYPE overrides the default."""
+
+    def __init__(self, num_blocks=(2, 2, 2, 2), num_classes=10, act_dtype=None):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 3, 1, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -46,20 +85,62 @@ class ResNet(nn.Module):
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.linear = nn.Linear(512, num_classes)
         self.pooling = nn.AdaptiveAvgPool2d((1, 1))
+        self.num_blocks = tuple(num_blocks)
+        self.act_dtype = act_dtype if act_dtype is not None else os.environ.get("DVAE_ACT_DTYPE", "f32")
+        self._engine = None
+        self._versions = None
+        object.__setattr__(self, "_anchor", torch.zeros((), requires_grad=True))
 
     def cam_register(self, layer="layer4"):
         """Kept for call compatibility (main_vae_disentangle.py:439 registers Grad-CAM hooks on model_c that nothing on
         the D-VAE path reads): records the layer name only."""
         self.cam_grad_layer = layer
 
+    # ---- device trunk ----------------------------------------------------------------------------
+    def _trunk_tensors(self):
+        named = dict(self.named_parameters())
+        named.update(dict(self.named_buffers()))
+        return {n: t for n, t in named.items() if not n.startswith("linear.")}
+
+    def _engine_for(self, x):
+        from . import _lib as L
+        from .model import _dtype_code
+        from .trunk import ResNetTrunkEngine
+        b, S = x.shape[0], x.shape[-1]
+        dtype = _dtype_code(self.act_dtype)
+        eng = self._engine
+        ok = (eng is not None and eng.B >= b and eng.S == S and eng.dev == x.device and eng.dtype == dtype and
+              eng.param["conv1.weight"] is self.conv1.weight)
+        if not ok:
+            t = self._trunk_tensors()
+            for n, v in t.items():
+                if v.device != x.device or (v.is_floating_point() and (v.dtype != torch.float32 or not v.is_contiguous())):
+                    raise RuntimeError(f"{n}: the device trunk needs contiguous fp32 parameters on {x.device}")
+            params = {n: v for n, v in t.items() if isinstance(v, nn.Parameter)}
+            buffers = {n: v for n, v in t.items() if not isinstance(v, nn.Parameter)}
+            eng = self._engine = ResNetTrunkEngine(self.num_blocks, params, buffers, max(b, eng.B if eng is not None else 0),
+                                                   x.device, dtype, S)
+            self._nbt_list = [v for n, v in buffers.items() if n.endswith("num_batches_tracked")]
+            self._versions = None
+        # parameters stepped by an optimiser / loaded / edited in place bump their version counters: re-pack, re-fold
+        # (writes through ``param.data`` do not: call ``model._engine.invalidate()`` after those)
+        v = tuple(t._version for t in eng.param.values()) + tuple(t._version for t in eng.buffers.values())
+        if v != self._versions:
+            eng.invalidate()
+            self._versions = v
+        return eng
+
     def forward(self, x):
-        out = F.relu(self.bn1(self.conv1(x)))
-        out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
+        if x.is_cuda:
+            out = _TrunkFunction.apply(self, x, self._anchor)
+        else:
+            out = F.relu(self.bn1(self.conv1(x)))
+            out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
         return self.linear(self.pooling(out).flatten(1))
 
 
-def ResNet18(num_classes=10):
-    return ResNet((2, 2, 2, 2), num_classes=num_classes)
+def ResNet18(num_classes=10, act_dtype=None):
+    return ResNet((2, 2, 2, 2), num_classes=num_classes, act_dtype=act_dtype)
 
 
 def accuracy(output, target, topk=(1,)):

@@ -19,10 +19,24 @@ import torch
 import torch.distributed as dist
 
 
+_SOLO = [False]
+
+
 def world_info():
-    if dist.is_available() and dist.is_initialized():
+    if not _SOLO[0] and dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+class solo:
+    """Inside the block this process sees itself as a job of one rank (``world_info()`` answers (0, 1)) although a
+    process group exists: for timing a one-rank pass inside a multi-rank job, while the other ranks wait at a barrier."""
+
+    def __enter__(self):
+        self.prev, _SOLO[0] = _SOLO[0], True
+
+    def __exit__(self, *a):
+        _SOLO[0] = self.prev
 
 
 def init_from_env(backend: str | None = None):

@@ -114,8 +114,12 @@ def recipe_params(cfg: DVAEConfig, scale_overrides: dict | None = None):
     (kaiming_uniform(a=sqrt 5) => U(-1/sqrt(fan_in), 1/sqrt(fan_in)); Embedding ~ N(0,1)) while
     BatchNorm affine/running statistics are perturbed away from their trivial defaults.
     """
+    return _recipe_fill(param_shapes(cfg), scale_overrides)
+
+
+def _recipe_fill(shapes: dict, scale_overrides: dict | None = None):
     out = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in shapes.items():
         rng = np.random.default_rng(zlib.crc32(name.encode()))
         if name.endswith("running_var"):
             a = rng.uniform(0.5, 1.5, shape)
@@ -127,8 +131,10 @@ def recipe_params(cfg: DVAEConfig, scale_overrides: dict | None = None):
             a = rng.standard_normal(shape)
         else:
             wname = name.rsplit(".", 1)[0] + ".weight"
-            wshape = param_shapes(cfg)[wname]
-            fan_in = wshape[1] * wshape[2] * wshape[3]   # torch's fan_in: size(1) * receptive field
+            wshape = shapes[wname]
+            fan_in = 1
+            for v in wshape[1:]:
+                fan_in *= v                               # torch's fan_in: size(1) * receptive field
             b = 1.0 / math.sqrt(fan_in)
             a = rng.uniform(-b, b, shape)
         if scale_overrides and name in scale_overrides:
@@ -174,6 +180,75 @@ class _MaskedReLU(torch.autograd.Function):
         return g * mask.to(g.dtype), None
 
 
+# --- bf16-storage emulation -------------------------------------------------------------------
+# The device path's bf16 mode keeps activations, gradient maps and packed weights in bf16 and everything else (sums,
+# statistics, parameters, parameter gradients, losses) in fp32.  Inside ``with bf16_storage():`` the functions below
+# round to bf16 at exactly those storage points -- forward values and the gradients that flow back through them -- so that
+# the bf16 path can be held to a reference that differs from it by summation order only, instead of to the fp32 result
+# through a loose bound.  Outside the block nothing changes (the reference is fp32 throughout).
+_BF16_STORAGE = [False]
+
+
+class bf16_storage:
+    def __enter__(self):
+        self.prev, _BF16_STORAGE[0] = _BF16_STORAGE[0], True
+
+    def __exit__(self, *a):
+        _BF16_STORAGE[0] = self.prev
+
+
+def _r16(t):
+    return t.bfloat16().float()
+
+
+class _RoundBoth(torch.autograd.Function):
+    """A tensor stored in bf16: the value is rounded, and so is the gradient that arrives for it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _r16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """A packed bf16 copy of an fp32 master tensor (weights, the embedding table): rounded value, fp32 gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _r16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """An fp32 tensor whose gradient map is stored in bf16 (decoder outputs, mu | log_var)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+def _st(x):
+    return _RoundBoth.apply(x) if _BF16_STORAGE[0] else x
+
+
+def _wq(w):
+    return _RoundFwd.apply(w) if _BF16_STORAGE[0] else w
+
+
+def _gq(x):
+    return _RoundBwd.apply(x) if _BF16_STORAGE[0] else x
+
+
 def _relu(x, name, masks, pre):
     if pre is not None:
         pre[name] = x.detach()
@@ -199,20 +274,22 @@ def _bn(p, prefix, x, train: bool, new_stats: dict | None):
 
 def _basic_block(p, blk, x, train, new_stats, masks=None, pre=None):
     """BasicBlock.forward, resnet.py:26-31."""
-    stride = 2 if blk == "layer2.0" else 1
-    out = _relu(_bn(p, blk + ".bn1", F.conv2d(x, p[blk + ".conv1.weight"], None, stride, 1), train, new_stats),
-                blk + ".bn1.out", masks, pre)
-    out = _bn(p, blk + ".bn2", F.conv2d(out, p[blk + ".conv2.weight"], None, 1, 1), train, new_stats)
+    stride = 2 if blk in ("layer2.0", "layer3.0", "layer4.0") else 1
+    out = _st(F.conv2d(x, _wq(p[blk + ".conv1.weight"]), None, stride, 1))
+    out = _st(_relu(_bn(p, blk + ".bn1", out, train, new_stats), blk + ".bn1.out", masks, pre))
+    out = _bn(p, blk + ".bn2", _st(F.conv2d(out, _wq(p[blk + ".conv2.weight"]), None, 1, 1)), train, new_stats)
     if (blk + ".shortcut.0.weight") in p:
-        sc = _bn(p, blk + ".shortcut.1", F.conv2d(x, p[blk + ".shortcut.0.weight"], None, stride, 0), train, new_stats)
+        sc = _st(F.conv2d(x, _wq(p[blk + ".shortcut.0.weight"]), None, stride, 0))
+        sc = _st(_bn(p, blk + ".shortcut.1", sc, train, new_stats))
     else:
         sc = x
-    return _relu(out + sc, blk + ".out", masks, pre)
+    return _st(_relu(out + sc, blk + ".out", masks, pre))
 
 
 def forward_stem(p, cfg, x, train, new_stats=None, masks=None, pre=None):
     """resnet.py:2139-2150."""
-    out = _relu(_bn(p, "bn1", F.conv2d(x, p["conv1.weight"], None, 1, 1), train, new_stats), "bn1.out", masks, pre)
+    out = _st(F.conv2d(_st(x), _wq(p["conv1.weight"]), None, 1, 1))
+    out = _st(_relu(_bn(p, "bn1", out, train, new_stats), "bn1.out", masks, pre))
     for blk in block_names(cfg):
         out = _basic_block(p, blk, out, train, new_stats, masks, pre)
     return out
@@ -220,12 +297,12 @@ def forward_stem(p, cfg, x, train, new_stats=None, masks=None, pre=None):
 
 def _decoder(p, d, z, sigmoid: bool, masks=None, pre=None):
     """resnet.py:2011-2028 (decoder) / :2033-2050 (decoder_p, no sigmoid)."""
-    h = F.conv_transpose2d(z, p[d + "1.0.weight"], p[d + "1.0.bias"], stride=2, padding=1)
-    h = F.conv_transpose2d(h, p[d + "1.1.weight"], p[d + "1.1.bias"], stride=1, padding=1)
-    h = _relu(F.instance_norm(h, eps=IN_EPS), d + ".d3", masks, pre)
-    h = F.conv_transpose2d(h, p[d + "2.0.weight"], p[d + "2.0.bias"], stride=1, padding=1)
-    h = _relu(F.instance_norm(h, eps=IN_EPS), d + ".d5", masks, pre)
-    h = F.conv_transpose2d(h, p[d + "3.0.weight"], p[d + "3.0.bias"], stride=1, padding=1)
+    h = _st(F.conv_transpose2d(z, _wq(p[d + "1.0.weight"]), p[d + "1.0.bias"], stride=2, padding=1))
+    h = _st(F.conv_transpose2d(h, _wq(p[d + "1.1.weight"]), p[d + "1.1.bias"], stride=1, padding=1))
+    h = _st(_relu(F.instance_norm(h, eps=IN_EPS), d + ".d3", masks, pre))
+    h = _st(F.conv_transpose2d(h, _wq(p[d + "2.0.weight"]), p[d + "2.0.bias"], stride=1, padding=1))
+    h = _st(_relu(F.instance_norm(h, eps=IN_EPS), d + ".d5", masks, pre))
+    h = _gq(F.conv_transpose2d(h, _wq(p[d + "3.0.weight"]), p[d + "3.0.bias"], stride=1, padding=1))
     return torch.sigmoid(h) if sigmoid else h
 
 
@@ -236,19 +313,20 @@ def forward(p, cfg: DVAEConfig, x, y, eps, train: bool, new_stats: dict | None =
     ``randn * 0.0`` on the input (:2206-2207) is a numeric no-op and is dropped.
     """
     stem_out = forward_stem(p, cfg, x, train, new_stats, masks, pre)
-    mu = F.conv2d(stem_out, p["fc_mu.weight"], p["fc_mu.bias"])
-    log_var = F.conv2d(stem_out, p["fc_var.weight"], p["fc_var.bias"])
-    z1 = eps * torch.exp(0.5 * log_var) + mu
-    z = F.conv2d(z1, p["post_conv.weight"], p["post_conv.bias"])
+    mu = _gq(F.conv2d(stem_out, _wq(p["fc_mu.weight"]), p["fc_mu.bias"]))
+    log_var = _gq(F.conv2d(stem_out, _wq(p["fc_var.weight"]), p["fc_var.bias"]))
+    z1 = _st(eps * torch.exp(0.5 * log_var) + mu)
+    z = _st(F.conv2d(z1, _wq(p["post_conv.weight"]), p["post_conv.bias"]))
     rec = _decoder(p, "decoder", z, True, masks, pre)
+    table = _wq(p["emb_p.weight"])
     if cfg.spatial_emb:
-        emb = p["emb_p.weight"][y].reshape(stem_out.shape)
+        emb = table[y].reshape(stem_out.shape)
     else:
-        emb = p["emb_p.weight"][y][:, :, None, None].repeat(1, 1, stem_out.shape[2], stem_out.shape[3])
+        emb = table[y][:, :, None, None].repeat(1, 1, stem_out.shape[2], stem_out.shape[3])
     if cfg.sample_wise:
-        dec_in = emb + (stem_out if cfg.use_y else z)
+        dec_in = _st(emb + (stem_out if cfg.use_y else z))
     else:
-        dec_in = emb
+        dec_in = _st(emb)
     perturbation = _decoder(p, "decoder_p", dec_in, False, masks, pre)
     return {"stem_out": stem_out, "mu": mu, "log_var": log_var, "z1": z1, "z": z,
             "rec": rec, "perturbation": perturbation}
@@ -420,3 +498,62 @@ def poison_u8(data_u8: np.ndarray, perturbation: torch.Tensor, targets=None, poi
         out[i] = out[i] + noise
         out[i] = np.clip(out[i], a_min=0, a_max=255)
     return out.astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------------
+# classifier stage: CIFAR ResNet-18 (resnet.py:62-122) and its train step (main_vae_disentangle.py:97-125)
+# --------------------------------------------------------------------------------------------
+RESNET18_BLOCKS = [f"layer{i}.{j}" for i in (1, 2, 3, 4) for j in (0, 1)]
+
+
+def resnet18_shapes(num_classes: int = 10):
+    """name -> shape of ResNet18's parameters and BatchNorm statistics, reference state_dict names."""
+    s = {"conv1.weight": (64, 3, 3, 3)}
+
+    def bn(prefix, c):
+        for k, shape in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,))):
+            s[prefix + "." + k] = shape
+
+    bn("bn1", 64)
+    cin = 64
+    for blk in RESNET18_BLOCKS:
+        c = 64 << (int(blk[5]) - 1)
+        s[blk + ".conv1.weight"] = (c, cin, 3, 3)
+        bn(blk + ".bn1", c)
+        s[blk + ".conv2.weight"] = (c, c, 3, 3)
+        bn(blk + ".bn2", c)
+        if cin != c:
+            s[blk + ".shortcut.0.weight"] = (c, cin, 1, 1)
+            bn(blk + ".shortcut.1", c)
+        cin = c
+    s["linear.weight"] = (num_classes, 512)
+    s["linear.bias"] = (num_classes,)
+    return s
+
+
+def resnet18_recipe(num_classes: int = 10, scale_overrides: dict | None = None):
+    """The closed-form fill of recipe_params for the classifier's tensors."""
+    return _recipe_fill(resnet18_shapes(num_classes), scale_overrides)
+
+
+def resnet18_forward(p, x, train: bool, new_stats: dict | None = None, masks=None, pre=None):
+    """ResNet.forward (resnet.py:107-118): conv1-bn1-relu, four stages of two BasicBlocks, 4x4 average pool, linear."""
+    out = _st(F.conv2d(_st(x), _wq(p["conv1.weight"]), None, 1, 1))
+    out = _st(_relu(_bn(p, "bn1", out, train, new_stats), "bn1.out", masks, pre))
+    for blk in RESNET18_BLOCKS:
+        out = _basic_block(p, blk, out, train, new_stats, masks, pre)
+    feat = out
+    out = F.adaptive_avg_pool2d(_gq(out), 1).flatten(1)   # (the trunk's output leaves the device path as fp32)
+    return F.linear(out, p["linear.weight"], p["linear.bias"]), feat
+
+
+def resnet18_train_grads(p, x, y, masks=None):
+    """Forward in train mode, cross-entropy, backward (main_vae_disentangle.py:100-107): logits, loss, gradients by
+    name and the BatchNorm running statistics after the step."""
+    p = {k: (v.clone().requires_grad_(True) if not is_buffer(k) else v.clone()) for k, v in p.items()}
+    stats = {}
+    logits, _ = resnet18_forward(p, x, True, stats, masks)
+    loss = F.cross_entropy(logits, y)
+    names = [k for k in p if not is_buffer(k)]
+    grads = torch.autograd.grad(loss, [p[k] for k in names])
+    return logits.detach(), float(loss.detach()), dict(zip(names, grads)), stats

@@ -422,12 +422,50 @@ def gen_resnet18_keys(ref):
     print("resnet18_state_dict_keys.json", len(net.state_dict()))
 
 
+def resnet18_inputs(B=8, seed=777):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, 3, 32, 32, generator=g), (torch.arange(B) * 3 + 1) % 10
+
+
+def gen_resnet18_step(ref):
+    """The classifier stage's arithmetic on the reference's own module (resnet.py:62-122): ResNet18(10) filled from the
+    closed-form recipe, one train-mode forward of 8 images + CrossEntropyLoss + backward as Trainer.train_batch runs them
+    (main_vae_disentangle.py:100-107; the clip and the SGD step are torch's own and not restated), and an eval-mode
+    forward with the recipe's running statistics.  Stored: logits, loss, every gradient's L2 norm, four gradients as
+    strided subsamples, four BatchNorm running statistics after the train forward."""
+    out = {}
+    x, y = resnet18_inputs()
+    params = O.resnet18_recipe(10)
+    net = ref.ResNet18(num_classes=10)
+    missing, unexpected = net.load_state_dict(params, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    net.eval()
+    with torch.no_grad():
+        out["eval.logits"] = net(x).numpy()
+    net.train()
+    logits = net(x)
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    out["train.logits"] = logits.detach().numpy()
+    out["train.loss"] = np.float64(loss.item())
+    for k, v in net.named_parameters():
+        out["gnorm." + k] = np.float64(v.grad.double().norm())
+    for k in ("conv1.weight", "layer2.0.shortcut.0.weight", "layer3.1.conv2.weight", "layer4.0.conv1.weight", "layer4.1.bn2.weight",
+              "linear.weight"):
+        out["gsub." + k] = dict(net.named_parameters())[k].grad.reshape(-1)[::SUB].numpy().copy()
+    sd = net.state_dict()
+    for k in ("bn1.running_mean", "layer1.1.bn2.running_var", "layer3.0.shortcut.1.running_mean", "layer4.1.bn2.running_var"):
+        out["stat." + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g7_resnet18_step.npz"), **out)
+    print("g7_resnet18_step.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = load_reference()
     gens = {"forward": gen_forward, "loss_grads": gen_loss_grads, "trajectory": gen_trajectory, "purify": gen_purify,
             "purify64": gen_purify64, "purify224": gen_purify224, "dp_step": gen_dp_step, "quant_kat": lambda r: gen_quant_kat(),
-            "state_dict_keys": gen_state_dict_keys, "resnet18_keys": gen_resnet18_keys}
+            "state_dict_keys": gen_state_dict_keys, "resnet18_keys": gen_resnet18_keys, "resnet18_step": gen_resnet18_step}
     for name in (sys.argv[1:] or list(gens)):       # no arguments: regenerate everything
         gens[name](ref)

@@ -48,6 +48,13 @@ CONVS = [
     (32, 3, 3, 1, 1, True, 96, True),         # LDS-weights kernel, 32 stored input channels
     (3, 64, 3, 1, 1, False, 96, False),       # first conv
     (64, 64, 3, 1, 1, False, 224, False),
+    # the classifier's layer3 / layer4 shapes (resnet.py:62-122)
+    (128, 256, 3, 2, 1, False, 16, False),
+    (256, 256, 3, 1, 1, False, 8, False),
+    (128, 256, 1, 2, 0, False, 16, False),
+    (256, 512, 3, 2, 1, False, 8, False),
+    (512, 512, 3, 1, 1, False, 4, False),
+    (256, 512, 1, 2, 0, False, 8, False),
 ]
 
 
@@ -124,11 +131,20 @@ def test_model_forward_bf16(train):
 
 @pytest.mark.parametrize("B", [8, 128])
 def test_train_step_bf16_tracks_fp32(B):
-    """Losses and gradients of one step, bf16 engine vs the fp32 oracle (gate open, epoch 11, stage 1); at 8 images
-    and at the reference's batch of 128 (configs/cifar10/resnet18DVAE.yaml), where the backward kernels loop over tiles."""
+    """Losses and gradients of one step of the bf16 engine (gate open, epoch 11, stage 1), at 8 images and at the
+    reference's batch of 128 (configs/cifar10/resnet18DVAE.yaml), where the backward kernels loop over tiles.
+    The bounds are derived from bf16 rounding itself: the oracle runs a second time with every tensor the device path
+    stores in bf16 (activations, gradient maps, packed weights, the embedding table) rounded at the same points
+    (oracle.bf16_storage) and fp32 everywhere else.  Against that emulation the loss scalars must agree to 2e-4 (3e-2
+    against fp32 before).  Parameter gradients: BatchNorm's and InstanceNorm's backward subtract the common mode of a
+    gradient map, which amplifies the rounding of the stored maps -- the emulation itself is 0.05-0.2 (relative L2) away
+    from the fp32 gradient per tensor -- so every tensor of the device path must be no further from fp32 than 1.3 x the
+    emulation is (+ 1e-2) and no further from the emulation than the emulation is from fp32 (+ 1e-2)."""
     ocfg, eng, p = _engine(L.BF16, B)
     x, y, eps = O.make_inputs(ocfg, B)
     info, grads, _ = O.train_step({k: v.clone() for k, v in p.items()}, ocfg, x, y, eps, {}, 11, 1)
+    with O.bf16_storage():
+        info16, grads16, _ = O.train_step({k: v.clone() for k, v in p.items()}, ocfg, x, y, eps, {}, 11, 1)
     x0 = eng.input_from_nchw(x.cuda())
     e = eng.eps_from_nchw(eps.cuda())
     eng.forward(x0, y.cuda(), e, B, True)
@@ -137,14 +153,23 @@ def test_train_step_bf16_tracks_fp32(B):
     eng.backward()
     s = eng.scal.cpu().numpy()
     for k in ("loss", "loss_rec", "loss_rec_p", "loss_p", "kld"):
-        assert abs(s[L.SCAL[k]] - info[k]) <= 3e-2 * abs(info[k]), (k, s[L.SCAL[k]], info[k])
-    for k in ("fc_mu.weight", "fc_var.bias", "post_conv.weight", "decoder1.0.weight", "decoder_p3.0.weight", "emb_p.weight",
-              "layer2.0.conv2.weight", "layer1.0.conv1.weight", "conv1.weight", "bn1.weight", "layer2.0.bn2.bias"):
-        assert l2_err(eng.grad[k].cpu(), grads[k]) < 0.25, k
+        assert abs(s[L.SCAL[k]] - info16[k]) <= 2e-4 * abs(info16[k]), (k, s[L.SCAL[k]], float(info16[k]))
+        assert abs(s[L.SCAL[k]] - info[k]) <= 2e-3 * abs(info[k]), (k, s[L.SCAL[k]], float(info[k]))
     live = [k for k in grads if not (k.endswith("1.1.bias") or k.endswith("2.0.bias"))]
+    worst = (0.0, "")
+    for k in live:
+        dev = eng.grad[k].cpu()
+        e_dev, e_emu, d = l2_err(dev, grads[k]), l2_err(grads16[k], grads[k]), l2_err(dev, grads16[k])
+        assert e_dev <= 1.3 * e_emu + 1e-2, (k, e_dev, e_emu)
+        assert d <= e_emu + 1e-2, (k, d, e_emu)
+        worst = max(worst, (e_dev, k))
     a = torch.cat([eng.grad[k].flatten().cpu().double() for k in live])
     b = torch.cat([grads[k].flatten().double() for k in live])
-    assert float((a * b).sum() / a.norm() / b.norm()) > 0.998
+    c = torch.cat([grads16[k].flatten().double() for k in live])
+    cos = lambda u, v: float((u * v).sum() / u.norm() / v.norm())      # noqa: E731
+    print(f"bf16 step, batch {B}: whole-gradient cosine device/fp32 {cos(a, b):.5f}, emulation/fp32 {cos(c, b):.5f}, "
+          f"device/emulation {cos(a, c):.5f}; worst tensor vs fp32 {worst}")
+    assert cos(a, b) > 0.998 and cos(a, c) > 0.998
     eng.adam_step()
     assert np.isfinite(float(eng.scal[L.SCAL["grad_norm"]]))
 

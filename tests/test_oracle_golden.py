@@ -214,3 +214,29 @@ def test_data_parallel_step_matches_reference(golden_dir):
     p1 = O.recipe_params(cfg)
     info1, _, _ = O.train_step(p1, cfg, x, y, eps, {}, 11, 1)
     assert abs(info1["loss"] - info["loss"]) > 1e-6
+
+
+def resnet18_inputs(B=8, seed=777):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, 3, 32, 32, generator=g), (torch.arange(B) * 3 + 1) % 10
+
+
+def test_resnet18_step_matches_reference(golden_dir):
+    """The classifier stage's restatement (ResNet-18 forward, cross-entropy, backward) against the fixture made with
+    the reference's own module (tests/golden/make_golden.py::gen_resnet18_step)."""
+    g = np.load(os.path.join(golden_dir, "g7_resnet18_step.npz"))
+    p = O.resnet18_recipe(10)
+    x, y = resnet18_inputs()
+    with torch.no_grad():
+        lg, _ = O.resnet18_forward(p, x, False)
+    close(lg.numpy(), g["eval.logits"])
+    logits, loss, grads, stats = O.resnet18_train_grads(p, x, y)
+    close(logits.numpy(), g["train.logits"])
+    close(loss, g["train.loss"])
+    for k, v in grads.items():
+        close(float(v.double().norm()), g["gnorm." + k], 1e-4)
+    for k in ("conv1.weight", "layer2.0.shortcut.0.weight", "layer3.1.conv2.weight", "layer4.0.conv1.weight", "layer4.1.bn2.weight",
+              "linear.weight"):
+        close(grads[k].reshape(-1)[::SUB].numpy(), g["gsub." + k], 1e-4)
+    for k in ("bn1.running_mean", "layer1.1.bn2.running_var", "layer3.0.shortcut.1.running_mean", "layer4.1.bn2.running_var"):
+        close(stats[k].numpy(), g["stat." + k])
