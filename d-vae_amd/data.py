@@ -79,12 +79,13 @@ def synthetic_separable(n=50000, size=32, classes=10, seed=0, template_seed=1234
     return ArrayDataset(out, y)
 
 
-def synthetic_classwise_poison(classes=10, size=32, eps=8.0 / 255, seed=0):
+def synthetic_classwise_poison(classes=10, size=32, eps=8.0 / 255, seed=0, grid=8):
     """A class-wise shortcut perturbation in the ``perturbation.pt`` layout ([classes,3,H,W] float, values +-eps): a
-    random +-eps pattern on an 8x8 grid per class, as error-minimising noise is up to its L-inf bound."""
+    random +-eps pattern on a ``grid`` x ``grid`` lattice per class (8: blocks of 4 x 4 pixels; ``size``: every pixel its
+    own sign), as error-minimising noise is up to its L-inf bound."""
     rng = np.random.default_rng(seed)
-    g = rng.choice([-1.0, 1.0], (classes, 3, 8, 8)).astype(np.float32)
-    p = np.kron(g, np.ones((size // 8, size // 8), dtype=np.float32))
+    g = rng.choice([-1.0, 1.0], (classes, 3, grid, grid)).astype(np.float32)
+    p = np.kron(g, np.ones((size // grid, size // grid), dtype=np.float32))
     return torch.from_numpy(p * eps)
 
 

@@ -68,18 +68,18 @@ def train_dvae(ds, test, dtype, epochs, seed=2):
     return m, {k: round(p[k], 4) for k in ("loss_rec", "loss_rec_p", "loss_p", "kld_loss")}
 
 
-settings = [tuple(float(v) for v in s.split(",")) for s in sys.argv[1:]] or [(1.0, 0.25, 0.05)]
+settings = [tuple(float(v) for v in s.split(",")) for s in sys.argv[1:]] or [(1.0, 0.25, 0.05, 8, 8)]
 N, NT, CE = 4096, 8192, int(os.environ.get("CE", "8"))
-for sep, clutter, noise in settings:
-    tag = f"sep={sep} clutter={clutter} noise={noise}"
+for sep, clutter, noise, eps255, grid in settings:
+    tag = f"sep={sep} clutter={clutter} noise={noise} eps={eps255}/255 grid={int(grid)}"
     clean = DD.synthetic_separable(n=N, seed=21, separation=sep, clutter=clutter, noise=noise)
     test = DD.synthetic_separable(n=NT, seed=22, separation=sep, clutter=clutter, noise=noise)
     ds = DD.ArrayDataset(clean.data.copy(), clean.targets.copy())
-    DD.poison_dataset(ds, DD.synthetic_classwise_poison(10, 32, 8 / 255, seed=3), "classwise")
+    DD.poison_dataset(ds, DD.synthetic_classwise_poison(10, 32, eps255 / 255, seed=3, grid=int(grid)), "classwise")
     t0 = time.time()
-    print(tag, "clean", [classifier_acc(clean.data, clean.targets, test, CE, s) for s in (1, 1, 2)], flush=True)
+    print(tag, "clean", [classifier_acc(clean.data, clean.targets, test, CE, s) for s in (1, 2)], flush=True)
     print(tag, "poisoned", [classifier_acc(ds.data, ds.targets, test, CE, s) for s in (1, 2)], "t", round(time.time() - t0, 1), flush=True)
-    for dt in ("f32", "bf16"):
+    for dt in (() if os.environ.get("NO_DVAE") else ("f32", "bf16")):
         t0 = time.time()
         m, pay = train_dvae(ds, test, dt, int(os.environ.get("VE", "30")))
         t1 = time.time()

@@ -381,29 +381,109 @@ def test_two_stage_runner_tiny(tmp_path, monkeypatch):
     assert torch.equal(n0, torch.load(os.path.join(exp, "perturbation0.pt"), weights_only=True))
 
 
-def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
-    """The third correctness leg, as far as it can be checked without CIFAR: on a class-separable synthetic set with a
-    class-wise shortcut poison, a briefly trained D-VAE purifies the train set (stage 1: rec(x - p)) three ways -- the CPU
-    oracle, the fp32 HIP path and the bf16 HIP path, same parameters and same injected noise -- and a ResNet-18 trained
-    on each purified set (same initialisation, same batch order) must reach a clean test accuracy within +-1 % of the
-    oracle-purified run's."""
-    torch.manual_seed(0)
-    N, NT = 4096, 4096
-    clean = DD.synthetic_separable(n=N, seed=21)
-    test = DD.synthetic_separable(n=NT, seed=22)
-    ds = DD.ArrayDataset(clean.data.copy(), clean.targets.copy())
-    DD.poison_dataset(ds, DD.synthetic_classwise_poison(10, 32, 8 / 255, seed=3), "classwise")
-    # train a D-VAE briefly on the poisoned set (fp32, fused route)
+# The stand-in for CIFAR of the third correctness leg (no dataset can be fetched here), tuned until it can fail: class
+# templates pulled 40 % towards their mean under a class-independent clutter field (a ResNet-18 trained 20 epochs on the
+# 4096 clean images reaches about 85 % on clean test data, not 99), and a class-wise block pattern of +-16/255 as the
+# unlearnable-example shortcut (trained on the poisoned set the same classifier loses close to 30 points).
+PROXY = dict(separation=0.6, clutter=0.4, noise=0.1)
+POISON_EPS = 16 / 255
+CLASSIFIER_EPOCHS = 20
+
+
+def _classifier_accuracy(arr, targets, test, act_dtype="f32", seeds=(1,)):
+    return float(np.mean([_classifier_accuracy_once(arr, targets, test, act_dtype, s) for s in seeds]))
+
+
+def _classifier_accuracy_once(arr, targets, test, act_dtype, seed):
+    """Clean test accuracy of a ResNet-18 trained on (arr, targets) the way the classifier stage does it
+    (main_vae_disentangle.py:323-371: SGD 0.1 / 0.9 / 5e-4, cosine, RandomCrop(32, 4) + flip), same initialisation,
+    augmentation draws and batch order for every arm (per seed)."""
+    cfg = dvae_amd.config.from_dict(dict(dvae_amd.config.CIFAR10_RESNET18, epochs=CLASSIFIER_EPOCHS, log_frequency=100000))
+    torch.manual_seed(seed)
+    tds = DD.ArrayDataset(arr.copy(), targets.copy(), transform="crop_flip")
+    g2 = DD.DatasetGenerator(tds, test, train_batch_size=128, eval_batch_size=512, device="cuda", seed=6 + seed)
+    ld = g2.getDataLoader()
+    model = cfg.model(act_dtype=act_dtype).cuda()
+    optimizer = cfg.optimizer(model.parameters())
+    scheduler = cfg.scheduler(optimizer)
+    trainer = Trainer(cfg.criterion(), ld, None, cfg, datasets_generator=g2, iters=1)
+    ENV = new_env()
+    train(1, model, None, None, optimizer, scheduler, cfg.criterion(), trainer, Evaluator(ld, None, cfg), ENV, ld, cfg)
+    # mean over the last three epochs (small learning rates at the end of the cosine schedule): the +-1 point band is about
+    # three standard deviations of one evaluation's sampling noise on 16 384 test images
+    return float(np.mean(ENV["eval_history"][-3:]))
+
+
+def _train_dvae(ds, test, dtype, epochs=30):
+    """A D-VAE trained briefly on the poisoned set through the drop-in trainer (fused route), stage-1 constants."""
     gen = DD.DatasetGenerator(ds, test, train_batch_size=128, eval_batch_size=512, device="cuda", seed=2)
     loaders = gen.getDataLoader(train_shuffle=True, train_drop_last=True)
-    m = make_model()
+    torch.manual_seed(0)
+    m = make_model(dtype=dtype)
     m.train()
     opt = FusedAdam(m, lr=5e-3)
     tr = VAE_Trainer(loaders, None, Cfg(), stage=1, kd=3.0)
-    for epoch in range(30):                  # 960 steps: enough for reconstructions that keep the class templates
+    for epoch in range(epochs):                  # 960 steps
         for images, labels in loaders["train_dataset"]:
             tr.train_batch(images, labels, m, None, opt, epoch)
             tr.global_step += 1
+    return m
+
+
+def _purify_hip(sd, ds, eps, dt):
+    md = make_model(sd, dt)
+    md.eval()
+    N = len(ds)
+    eng = md._engine_for(torch.zeros(128, 3, 32, 32, device="cuda"))
+    d = torch.from_numpy(ds.data).cuda()
+    out = torch.zeros_like(d)
+    lab = torch.from_numpy(ds.targets).cuda()
+    for lo in range(0, N, 128):
+        eng.purify_batch(d, out, None, lab, lo, 128, 1, eps_nchw=(eps[0, lo:lo + 128].cuda(), eps[1, lo:lo + 128].cuda()))
+    return out.cpu().numpy()
+
+
+@torch.no_grad()
+def _purify_with_sign_error(sd, ds, eps):
+    """Stage-1 purification with ONE defect: the perturbation is added instead of subtracted
+    (main_vae_disentangle.py:62 with the sign flipped), everything else as the path does it."""
+    md = make_model(sd, "f32")
+    md.eval()
+    out = np.empty_like(ds.data)
+    for lo in range(0, len(ds), 128):
+        x = torch.from_numpy(ds.data[lo:lo + 128]).cuda().permute(0, 3, 1, 2).float().div(255)
+        y = torch.from_numpy(ds.targets[lo:lo + 128]).cuda()
+        _, _, _, _, pert = md(x, y, eps[0, lo:lo + 128].cuda())
+        x1 = (x + pert).clamp(0, 1)
+        _, rec, _, _, _ = md(x1, y, eps[1, lo:lo + 128].cuda())
+        out[lo:lo + 128] = (255 * rec.clamp(0, 1)).permute(0, 2, 3, 1).cpu().numpy().astype(np.uint8)
+    return out
+
+
+def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
+    """The third correctness leg, as far as it can be checked without CIFAR.  A D-VAE is trained briefly on a class-wise
+    poisoned stand-in set and purifies it (stage 1: rec(x - p)); a ResNet-18 is retrained on every version of the set and
+    evaluated on clean test data.  Arms, all with the same classifier initialisation and batch order:
+
+      clean        the unpoisoned set (what there is to recover)
+      poisoned     the poisoned set, unpurified: the control -- must lose >= 20 points against clean, else the poison is
+                   no shortcut and the leg shows nothing
+      oracle       purified by the CPU oracle with the fp32-trained D-VAE's parameters and injected noise
+      f32, bf16    the same parameters and noise through the fp32 / bf16 HIP purification: each within +-1 point of oracle
+      bf16-trained a D-VAE trained AND run in bf16 (what bench.py times): another trained network, so it is held to the
+                   claim that matters -- it purifies as well: >= oracle - 3 points
+      sign-error   the fp32 path with the perturbation added instead of subtracted: a purifier with one defect must land
+                   outside the +-1 band (below oracle by more than 3 points), else the leg could not see it
+    and the purified arms must recover >= 8 points over the poisoned control."""
+    torch.manual_seed(0)
+    N, NT = 4096, 16384
+    clean = DD.synthetic_separable(n=N, seed=21, **PROXY)
+    test = DD.synthetic_separable(n=NT, seed=22, **PROXY)
+    ds = DD.ArrayDataset(clean.data.copy(), clean.targets.copy())
+    DD.poison_dataset(ds, DD.synthetic_classwise_poison(10, 32, POISON_EPS, seed=3), "classwise")
+    accs = {"clean": _classifier_accuracy(clean.data, clean.targets, test),
+            "poisoned": _classifier_accuracy(ds.data, ds.targets, test)}
+    m = _train_dvae(ds, test, "f32")
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     ocfg = O.DVAEConfig()
     po = {k: sd[k].float() for k in O.param_shapes(ocfg)}
@@ -412,34 +492,28 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     purified["oracle"], _ = O.purify(po, ocfg, ds.data, ds.targets, lambda ps, lo, hi: eps[ps, lo:hi], 1, batch=128)
     for dt in ("f32", "bf16"):
-        md = make_model(sd, dt)
-        md.eval()
-        eng = md._engine_for(torch.zeros(128, 3, 32, 32, device="cuda"))
-        d = torch.from_numpy(ds.data).cuda()
-        out = torch.zeros_like(d)
-        lab = torch.from_numpy(ds.targets).cuda()
-        for lo in range(0, N, 128):
-            eng.purify_batch(d, out, None, lab, lo, 128, 1, eps_nchw=(eps[0, lo:lo + 128].cuda(), eps[1, lo:lo + 128].cuda()))
-        purified[dt] = out.cpu().numpy()
+        purified[dt] = _purify_hip(sd, ds, eps, dt)
     dq = np.abs(purified["f32"].astype(int) - purified["oracle"].astype(int))
     assert dq.max() <= 1 and (dq != 0).mean() <= 0.005
-    accs = {}
-    cfg = dvae_amd.config.from_dict(dict(dvae_amd.config.CIFAR10_RESNET18, epochs=8, log_frequency=1000))
+    m16 = _train_dvae(ds, test, "bf16")
+    sd16 = {k: v.detach().cpu().clone() for k, v in m16.state_dict().items()}
+    purified["bf16-trained"] = _purify_hip(sd16, ds, eps, "bf16")
+    purified["sign-error"] = _purify_with_sign_error(sd, ds, eps)
     for tag, arr in purified.items():
-        torch.manual_seed(1)
-        tds = DD.ArrayDataset(arr.copy(), ds.targets.copy(), transform="crop_flip")
-        g2 = DD.DatasetGenerator(tds, test, train_batch_size=128, eval_batch_size=512, device="cuda", seed=7)
-        ld = g2.getDataLoader()
-        model = cfg.model().cuda()
-        optimizer = cfg.optimizer(model.parameters())
-        scheduler = cfg.scheduler(optimizer)
-        trainer = Trainer(cfg.criterion(), ld, None, cfg, datasets_generator=g2, iters=1)
-        ENV = new_env()
-        train(1, model, None, None, optimizer, scheduler, cfg.criterion(), trainer, Evaluator(ld, None, cfg), ENV, ld, cfg)
-        accs[tag] = ENV["eval_history"][-1]
-    print("clean test accuracy after training on purified data:", accs)
-    assert accs["oracle"] > 90.0, accs
+        # the three arms of the +-1 band: two classifier seeds each (1-LSB differences between two purified sets send two
+        # trainings apart chaotically; one run's noise is about half a point)
+        accs[tag] = _classifier_accuracy(arr, ds.targets, test, seeds=(1, 2) if tag in ("oracle", "f32", "bf16") else (1,))
+    # the classifier stage itself in bf16 on the oracle-purified set
+    accs["oracle, bf16 classifier"] = _classifier_accuracy(purified["oracle"], ds.targets, test, act_dtype="bf16")
+    print("clean test accuracy (%) of a ResNet-18 trained on each version of the set:",
+          {k: round(v, 2) for k, v in accs.items()})
+    assert accs["clean"] - accs["poisoned"] >= 20.0, accs
     assert abs(accs["f32"] - accs["oracle"]) <= 1.0 and abs(accs["bf16"] - accs["oracle"]) <= 1.0, accs
+    assert accs["bf16-trained"] >= accs["oracle"] - 3.0, accs
+    assert accs["sign-error"] < accs["oracle"] - 3.0, accs
+    for k in ("oracle", "f32", "bf16", "bf16-trained"):
+        assert accs[k] >= accs["poisoned"] + 8.0, accs
+    assert abs(accs["oracle, bf16 classifier"] - accs["oracle"]) <= 3.0, accs
 
 
 def test_device_to_host_staging_is_exact():
