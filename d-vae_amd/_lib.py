@@ -11,6 +11,7 @@ import torch
 F32, BF16 = 0, 1
 OP_FWD, OP_DGRAD = 0, 1
 NPARTIAL = 1024
+PHILOX_STREAM_16 = 0x80000000     # stream ids with this bit draw eight normals per Philox call from 16-bit uniforms
 SCAL_COUNT = 16
 SCAL = dict(loss=0, loss_rec=1, loss_rec_p=2, loss_p=3, kld=4, gate_kl=5, gate_p=6, grad_norm=7,
             c_rec=8, c_p=9, c_kl=10)

@@ -257,18 +257,30 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
             if (last_tap && ZF) {
                 // ---- mu (acc[0]) and log_var (acc[1]) of 32 latent channels: draw eps, park z in the patch ----
                 const uint64_t img = a.zkey.index ? (uint64_t)a.zkey.index[b] : (uint64_t)(a.zkey.first + b);
-                unsigned e0 = (unsigned)(wave * 32 + r) * (unsigned)a.zL + 32u * q + 4u * h;   // element in the image
+                unsigned e0 = (unsigned)(wave * 32 + r) * (unsigned)a.zL + 32u * q;   // first element of this lane pair's 32
                 // the counter does not depend on the image, so the first Philox round of every (slab, quad) is a loop
                 // invariant: hoisted, it would sit in 64 registers for the whole kernel
                 asm volatile("" : "+v"(e0));
+                if (a.zkey.stream_id & PHILOX_STREAM_16) {
+                    f32x4 e[4];
+                    philox_lane_quads(a.zkey, img, e0, h, e);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 e = philox_normal4(a.zkey, img, (e0 + 8u * g) >> 2);
-                    bf16x4 o;
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (bf16)(e[k] * __expf(0.5f * acc[1][4 * g + k]) + acc[0][4 * g + k]);
-                    *reinterpret_cast<bf16x4*>(stg + r * SRS + (8 * g + 4 * h) * 2) = o;
-                    __builtin_amdgcn_sched_barrier(0);     // one Philox chain at a time: registers, not latency, are short
+                        for (int k = 0; k < 4; ++k) o[k] = (bf16)(e[g][k] * __expf(0.5f * acc[1][4 * g + k]) + acc[0][4 * g + k]);
+                        *reinterpret_cast<bf16x4*>(stg + r * SRS + (8 * g + 4 * h) * 2) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 e = philox_normal4(a.zkey, img, (e0 + 8u * g + 4u * h) >> 2);
+                        bf16x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = (bf16)(e[k] * __expf(0.5f * acc[1][4 * g + k]) + acc[0][4 * g + k]);
+                        *reinterpret_cast<bf16x4*>(stg + r * SRS + (8 * g + 4 * h) * 2) = o;
+                        __builtin_amdgcn_sched_barrier(0);     // one Philox chain at a time: registers, not latency, are short
+                    }
                 }
                 wave_lds_fence();
             }

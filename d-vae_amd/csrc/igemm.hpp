@@ -382,14 +382,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
             const uint64_t img = a.zkey.index ? (uint64_t)a.zkey.index[b] : (uint64_t)(a.zkey.first + b);
             const long in_img = (long)(rr % a.zrpi) * a.zL;
 #pragma unroll
-            for (int j = 0; j < TN / 2; ++j)
+            for (int j = 0; j < TN / 2; ++j) {
+                f32x4 e4[4];                                 // (zc0 and in_img are multiples of 8: zL % 128 == 0)
+                philox_lane_quads(a.zkey, img, (uint32_t)(in_img + zc0 + 32 * j), h, e4);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = 32 * j + 8 * g + 4 * h;   // channel within the wave's ZC
                     const int nl = wn0 + cl;                 // tile column of mu; log_var sits ZC columns further
                     const f32x4 bm = *reinterpret_cast<const f32x4*>(ssl + BN + nl);
                     const f32x4 bl = *reinterpret_cast<const f32x4*>(ssl + BN + nl + ZC);
-                    const f32x4 e = philox_normal4(a.zkey, img, (uint32_t)((in_img + zc0 + cl) >> 2));
+                    const f32x4 e = e4[g];
                     bf16x4 qd;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
                     }
                     *reinterpret_cast<bf16x4*>(stg + r * SRS + cl * 2) = qd;
                 }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

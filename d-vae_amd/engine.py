@@ -234,6 +234,11 @@ class DVAEEngine:
         # post_conv can leave decoder_p's input (z + class embedding) behind as a second output
         self._fuse_emb = bool(cfg.sample_wise and not cfg.use_y and cfg.spatial_emb and
                               self.lib.dvae_conv_supports_emb_out(C.byref(self._desc(self.specs["post_conv"], 1)), dtype))
+        # Purification draws its reparameterisation noise in-kernel.  bf16 engines take it from a 16-bit-uniform stream
+        # (stream id bit 31: eight normals per Philox call, half the cost per normal; eps feeds a product that is rounded
+        # to bf16 there); fp32 engines from the 24-bit stream.  Settable: an fp32 engine with this set draws the same
+        # numbers as a bf16 one.
+        self.inference_noise16 = dtype == BF16
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
         self._overlap = self.dev.type == "cuda"   # weight gradients on a side stream (see _wgrad)
 
@@ -935,14 +940,15 @@ class DVAEEngine:
         gf = first if global_first is None else global_first
         y = labels[first:first + b]
         x0 = self.input_from_u8(data_u8, first, b)
-        eps = self.eps_from_nchw(eps_nchw[0]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=1)
+        n16 = L.PHILOX_STREAM_16 if self.inference_noise16 else 0
+        eps = self.eps_from_nchw(eps_nchw[0]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=1 | n16)
         _, p = self.forward(x0, y, eps, b, False, need_rec=not skip_unread)
         if stage == 0:
             check(self.lib.dvae_purify_quant(ptr(x0), ptr(p), 0, None, ptr(out_u8), int(first), b, S * S, self.dtype, L.stream()))
         else:
             x1 = self.act("x1", S, 3)
             check(self.lib.dvae_purify_quant(ptr(x0), ptr(p), 0, ptr(x1), None, 0, b, S * S, self.dtype, L.stream()))
-            eps = self.eps_from_nchw(eps_nchw[1]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=2)
+            eps = self.eps_from_nchw(eps_nchw[1]) if eps_nchw is not None else self.eps_philox(b, gf, stream_id=2 | n16)
             rec_pre, p = self.forward(x1, y, eps, b, False)
             # rec = sigmoid(rec_pre), clamp and quantise in one launch
             check(self.lib.dvae_purify_quant(ptr(rec_pre), None, 2, None, ptr(out_u8), int(first), b, S * S, self.dtype, L.stream()))

@@ -178,23 +178,31 @@ def test_bn_eval_matches_torch():
     assert rel_err(y.cpu(), ref) < 2e-5
 
 
-def test_philox_normal_moments_and_index_keying():
+@pytest.mark.parametrize("sid", [1, 0x80000001], ids=["24-bit uniforms", "16-bit uniforms"])
+def test_philox_normal_moments_and_index_keying(sid):
+    """Stream ids with bit 31 set draw eight normals per Philox call from 16-bit uniforms (the bf16 inference path's
+    noise): same keying, same moments, |eps| <= sqrt(-2 ln 2^-16) = 4.71."""
     lib = L.lib()
     B, per = 8, 65536
     a = torch.empty(B, per, device="cuda")
-    L.check(lib.dvae_philox_normal(a.data_ptr(), None, 100, B, per, 1234, 1, L.stream()))
+    L.check(lib.dvae_philox_normal(a.data_ptr(), None, 100, B, per, 1234, sid, L.stream()))
+    if sid >> 31:
+        assert float(a.abs().max()) <= 4.7096 + 1e-4
+        other = torch.empty(B, per, device="cuda")
+        L.check(lib.dvae_philox_normal(other.data_ptr(), None, 100, B, per, 1234, sid & 0x7fffffff, L.stream()))
+        assert not torch.equal(other, a)
     v = a.cpu().double()
     assert abs(float(v.mean())) < 5e-3 and abs(float(v.var()) - 1) < 1e-2
     assert abs(float((v ** 4).mean()) - 3) < 0.1
     # image 103 drawn alone equals row 3 of the batch: the stream is keyed by the global image index
     b = torch.empty(1, per, device="cuda")
-    L.check(lib.dvae_philox_normal(b.data_ptr(), None, 103, 1, per, 1234, 1, L.stream()))
+    L.check(lib.dvae_philox_normal(b.data_ptr(), None, 103, 1, per, 1234, sid, L.stream()))
     assert torch.equal(b[0], a[3])
     idx = torch.tensor([107, 100], dtype=torch.int32, device="cuda")
     c2 = torch.empty(2, per, device="cuda")
-    L.check(lib.dvae_philox_normal(c2.data_ptr(), idx.data_ptr(), 0, 2, per, 1234, 1, L.stream()))
+    L.check(lib.dvae_philox_normal(c2.data_ptr(), idx.data_ptr(), 0, 2, per, 1234, sid, L.stream()))
     assert torch.equal(c2[0], a[7]) and torch.equal(c2[1], a[0])
-    L.check(lib.dvae_philox_normal(b.data_ptr(), None, 103, 1, per, 1234, 2, L.stream()))
+    L.check(lib.dvae_philox_normal(b.data_ptr(), None, 103, 1, per, 1234, sid + 1, L.stream()))
     assert not torch.equal(b[0], a[3])
 
 
