@@ -190,12 +190,14 @@ def probe_roofline(dtype_name, probe_ms, Bp, px, S):
                 traffic=None, traffic_source=None)
     # HBM bytes per launch are a PMC figure (rocprofv3 --pmc, one counter per pass, of this same command with fewer steps):
     # not measurable inside this run, so the figure of the committed passes is reported when they are of this launch
-    tpath = os.path.join(ROOT, "profiles", f"r02_traffic_{dtype_name}.json")
+    tpath = os.path.join(ROOT, "profiles", f"r03_traffic_{dtype_name}.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", f"r02_traffic_{dtype_name}.json")
     if os.path.exists(tpath) and Bp == 1024 and S == 32:
         t = json.load(open(tpath))
         if kname in t.get("kernel", "").replace(", ", ","):
             roof["traffic"] = t.get("hbm_bytes")
-            roof["traffic_source"] = os.path.relpath(tpath, ROOT) + " (PMC passes of scripts/profile_r02.sh, not this run)"
+            roof["traffic_source"] = os.path.relpath(tpath, ROOT) + " (separate rocprofv3 --pmc passes of the same command, not this run)"
     return roof
 
 

@@ -244,9 +244,11 @@ def _staging(kind, key, make):
 
 
 def release_staging():
-    """Free every pinned staging buffer (and side stream) kept by purify_dataset's host drains."""
+    """Free every pinned staging buffer (and side stream, and the copy threads) kept by purify_dataset's host drains."""
     _STAGE.clear()
     _COPY_STREAM.clear()
+    while _POOL:
+        _POOL.pop().shutdown(wait=True)
 
 
 def _copy_stream():
@@ -287,19 +289,29 @@ def _to_host_chunked(src, dst, chunk_rows=4096):
     return dst
 
 
-def _copy_rows_parallel(dst, src, ranges, threads=8, chunk_rows=4096):
-    """dst[a:b] = src[a:b] for every (a, b) of ``ranges`` (host tensors of one shape and dtype), in chunks spread over a
-    few threads (the copies release the interpreter lock)."""
+_POOL = []
+
+
+def _pool():
+    """A few worker threads for host-side copies (tensor copies release the interpreter lock), kept for the process."""
+    if not _POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.append(ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2) // 2))))
+    return _POOL[0]
+
+
+def _copy_rows_parallel(dst, src, ranges, chunk_rows=4096, src_offset=0):
+    """dst[a:b] = src[a - src_offset : b - src_offset] for every (a, b) of ``ranges`` (host tensors of one row shape), in
+    chunks spread over the worker threads.  One thread moves about 10 GB/s -- and a fresh destination takes a page fault
+    per 4 KB on top -- which makes the float64 perturbations (25 MB per 1024 images) the slowest stage of a pass."""
     jobs = [(a0, min(b, a0 + chunk_rows)) for a, b in ranges for a0 in range(a, b, chunk_rows)]
     if not jobs:
         return
-    if len(jobs) == 1 or threads <= 1:
-        for a, b in jobs:
-            dst[a:b].copy_(src[a:b])
+    if len(jobs) == 1:
+        a, b = jobs[0]
+        dst[a:b].copy_(src[a - src_offset:b - src_offset])
         return
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(threads, len(jobs))) as ex:
-        list(ex.map(lambda ab: dst[ab[0]:ab[1]].copy_(src[ab[0]:ab[1]]), jobs))
+    list(_pool().map(lambda ab: dst[ab[0]:ab[1]].copy_(src[ab[0] - src_offset:ab[1] - src_offset]), jobs))
 
 
 class _HostDrain:
@@ -322,8 +334,8 @@ class _HostDrain:
     def _retire(self):
         ev, lo, hi, st = self.pending.pop(0)
         ev.synchronize()
-        for d, s in zip(self.dst, st):
-            d[lo:hi].copy_(s[:hi - lo])
+        self.dst[0][lo:hi].copy_(st[0][:hi - lo])
+        _copy_rows_parallel(self.dst[1], st[1], [(lo, hi)], chunk_rows=max(32, (hi - lo + 5) // 6), src_offset=lo)
         if self.also_u8 is not None:
             self.also_u8[lo:hi].copy_(st[0][:hi - lo])
 

@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 output of scripts/profile_r02.sh (gpurun_out/prof_r02) into the files kept under profiles/:
+"""Turn the rocprofv3 output of scripts/profile_r03.sh (gpurun_out/prof_r03; r02 likewise) into the files kept under profiles/:
   r02_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the default `python bench.py`
   r02_probe_kernel.json        the probed conv kernel's 1024-image launches in that trace (count, mean, min, max)
   r02_traffic_bf16.json        FETCH_SIZE / WRITE_SIZE of those launches (one counter per pass) and the HBM bytes they
@@ -11,12 +11,15 @@ import os
 import shutil
 import statistics as st
 
+import sys
+
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"       # usage: python scripts/summarize_profile.py [r02|r03]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
 K = "void dvae::conv_wreg_bf16_kernel<64, 64, 1, false>(dvae::HaloArgs)"
 
-shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, "r02_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, ROUND + "_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_trace.csv"))))
 us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"] == K]
 # the 1024-image launches: the train step's 128-image ones are 4x shorter, and a launch that pays a one-off cost (the
@@ -26,7 +29,7 @@ big = [x for x in us if 0.6 * p90 < x < 2.0 * p90]
 probe = {"kernel": K, "launches_1024_images": len(big), "mean_us": st.mean(big), "min_us": min(big), "max_us": max(big),
          "launches_all_shapes": len(us), "outliers_above_us": [x for x in us if x >= 2.0 * p90],
          "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py"}
-json.dump(probe, open(os.path.join(DST, "r02_probe_kernel.json"), "w"), indent=1)
+json.dump(probe, open(os.path.join(DST, ROUND + "_probe_kernel.json"), "w"), indent=1)
 
 
 def counter(name):
@@ -45,5 +48,5 @@ traffic = {"kernel": K, "launch": "3x3 conv 64->64 @32x32, 1024 images (purifica
            "hbm_bytes": (2 * f + w) * 1024, "algorithmic_bytes": 2 * 1024 * 1024 * 64 * 2,
            "commands": ["rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-train --no-f32 --no-pass --no-cpu-baseline",
                         "rocprofv3 --pmc WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-train --no-f32 --no-pass --no-cpu-baseline"]}
-json.dump(traffic, open(os.path.join(DST, "r02_traffic_bf16.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(DST, ROUND + "_traffic_bf16.json"), "w"), indent=1)
 print(json.dumps(probe), json.dumps(traffic))
