@@ -115,7 +115,7 @@ struct WregSched {
     int over;                                              // operations that found no gap with room (0 in a schedule that is used)
     int cap;                                               // the instructions-per-gap budget the schedule was built for
 };
-__host__ __device__ constexpr int wreg_op_cost(int kind, bool has_add) {
+__host__ __device__ constexpr int wreg_op_cost(int kind, bool has_add, bool in_ss = false, bool stats = false) {
     switch (kind) {
     case W_R: return 2;
     case W_EL: return has_add ? 3 : 2;
@@ -124,14 +124,14 @@ __host__ __device__ constexpr int wreg_op_cost(int kind, bool has_add) {
     case W_EB: return 3;
     case W_EC: return 2;
     case W_DL: return 1;
-    case W_DS: return 3;
+    case W_DS: return stats ? 27 : 3;                      // + sum and sum of squares of the piece's 8 channels
     case W_PARK: return 2;
     case W_HL: return 4;
-    case W_HS: return 2;
+    case W_HS: return in_ss ? 34 : 2;                      // + scale / shift / ReLU of the vector's 8 channels on its way to LDS
     default: return 0;
     }
 }
-template <int G, int TN, int KS, int NEPI, int NI, int NR, int HV, int HDIST, int G_MIN, bool HAS_ADD>
+template <int G, int TN, int KS, int NEPI, int NI, int NR, int HV, int HDIST, int G_MIN, bool HAS_ADD, bool IN_SS = false, bool STATS = false>
 __host__ __device__ constexpr WregSched<2 * G> wreg_try_sched(int CAP) {
     constexpr int G2 = 2 * G, LAT = 4;                     // LAT: gaps between an LDS read and the first use of its data
     WregSched<G2> s{};
@@ -145,7 +145,7 @@ __host__ __device__ constexpr WregSched<2 * G> wreg_try_sched(int CAP) {
     for (int g = G + 2; g < G + 10 && g < G2; g += 2) cap[g] = 0;         // the next tile's origin and masks are computed here
     s.over = 0;
     auto place = [&](int g, int gmax, int kind, int ix) -> int {        // first gap in [g, gmax) with room; books it
-        const int cost = wreg_op_cost(kind, HAS_ADD);
+        const int cost = wreg_op_cost(kind, HAS_ADD, IN_SS, STATS);
         int at = -1;
         for (int q = g; q < gmax; ++q) {
             // (an operation bigger than any gap goes to one nothing else has been booked into)
@@ -213,20 +213,25 @@ __host__ __device__ constexpr WregSched<2 * G> wreg_try_sched(int CAP) {
 }
 // The schedule for the smallest instructions-per-gap budget (from the 5 that are free) that places every operation: the
 // shapes with one MFMA per step cannot do with 5, and then the excess is spread over all gaps instead of piling up.
-template <int G, int TN, int KS, int NEPI, int NI, int NR, int HV, int HDIST, int G_MIN, bool HAS_ADD>
+template <int G, int TN, int KS, int NEPI, int NI, int NR, int HV, int HDIST, int G_MIN, bool HAS_ADD, bool IN_SS = false, bool STATS = false>
 __host__ __device__ constexpr WregSched<2 * G> wreg_make_sched() {
-    for (int cap = 5; cap < 16; ++cap) {
-        const auto s = wreg_try_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD>(cap);
+    for (int cap = 5; cap < 40; ++cap) {
+        const auto s = wreg_try_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD, IN_SS, STATS>(cap);
         if (s.over == 0) return s;
     }
-    return wreg_try_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD>(16);
+    return wreg_try_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD, IN_SS, STATS>(40);
 }
 
 // WTL: the last WTL taps' fragments are held in architectural VGPRs instead of the accumulator file (64 -> 64: nine taps
 // are 288 registers, the accumulator file has 256)
 // HAS_ADD: a residual / old-output tensor is added in the epilogue (compiled in, so that launches without one carry none
 // of its operations and branches)
-template <int CIN, int NT, int WTL, bool HAS_ADD>
+// IN_SS / STATS: the optional features of conv_halo.hpp's kernel, for launches that walk whole images (the launcher caps
+// the grid at the image count): the per-(image, channel) scale / shift (+ ReLU) of the normalisation in front of the conv
+// is applied to every halo vector on its way from registers to LDS (zero padding stays zero), and the sums / sums of
+// squares of the stored output are gathered from the drain pieces, one chunk per tile row (8 per image), flushed when a
+// workgroup has drained an image's last tile.
+template <int CIN, int NT, int WTL, bool HAS_ADD, bool IN_SS = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     constexpr int TW = 32, TH = 8, HWD = TW + 2, HP = (TH + 2) * HWD;
     constexpr int RS = CIN * 2 + 16;          // bytes per staged halo pixel (16-byte pad spreads banks)
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     // Tile order: with at least one image per workgroup a workgroup walks whole images (image j of workgroup g is
     // g + j * gridDim.x, tiles in order), so the two halo rows neighbouring tiles share are re-read from the cache level
     // that just served them; otherwise tiles are strided over the grid.
-    const bool imo = a.B >= (int)gridDim.x;
+    const bool imo = IN_SS || STATS || a.B >= (int)gridDim.x;    // (the feature launches have at most one workgroup per image)
     const int tgrp = imo ? tpi : 1;                                   // (one branch-free form for both orders)
     auto tile_at = [&](int i) -> int {
         const int j = imo ? a.g.div_tpi(i) : i;
@@ -335,9 +340,27 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     // instead of branching around the store.
     static_assert((HV - 1) * 256 < HP * VPP, "every vector but the last exists for every thread");
     unsigned char* hst_last = (m_valid >> (HV - 1) & 1u) ? hst + (HV - 1) * PSTEP * RS : smem + CIN * 2;
+    // input normalisation of this thread's 8 channels (chunk cv) for the image of the tile being fetched
+    f32x4 isc[2], ish[2];
+    const float in_lo = a.in_relu ? 0.f : -__builtin_inff();
+    auto load_in_ss = [&](int b) {
+        const float* p = a.in_ss + (long)b * 2 * CIN + cv * 8;
+        isc[0] = *reinterpret_cast<const f32x4*>(p); isc[1] = *reinterpret_cast<const f32x4*>(p + 4);
+        ish[0] = *reinterpret_cast<const f32x4*>(p + CIN); ish[1] = *reinterpret_cast<const f32x4*>(p + CIN + 4);
+    };
     auto store_halo_vec = [&](int buf, int k) {
         unsigned char* at = k < HV - 1 ? hst + k * PSTEP * RS : hst_last;
-        *reinterpret_cast<u32x4*>(at + buf * HALO_BYTES) = hreg[k];
+        u32x4 val = hreg[k];
+        if (IN_SS) {
+            bf16x8 x = __builtin_bit_cast(bf16x8, val);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = (bf16)fmaxf((float)x[c] * isc[c >> 2][c & 3] + ish[c >> 2][c & 3], in_lo);
+            const u32x4 nv = __builtin_bit_cast(u32x4, x);
+            const bool pad = __builtin_amdgcn_ubfe(hbad, k, 1) != 0;       // outside the image: the zero padding stays zero
+#pragma unroll
+            for (int c = 0; c < 4; ++c) val[c] = pad ? 0u : nv[c];
+        }
+        *reinterpret_cast<u32x4*>(at + buf * HALO_BYTES) = val;
     };
 
     // ---- weights: global -> LDS images (coalesced) -> this wave's A-operand fragments, once ------------------------
@@ -365,6 +388,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
             halo_tile(tile0);
 #pragma unroll
             for (int k = 0; k < HV; ++k) load_halo_vec(k);
+            if (IN_SS) load_in_ss(a.g.div_tpi(tile0));
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
@@ -489,6 +513,40 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     };
     auto park_add = [&](int i) { *reinterpret_cast<u32x4*>(rsg + (i * PPI + sp) * SRS + sc8 * 16) = radd[i]; };
 
+    // ---- output statistics: per lane (coalesced layout: pixel sp of a piece, 8-channel chunk sc8) the sums over the drained
+    // pieces of block 0 (tile row 2 wave: chunk 2 wave of the image) and of block 1 (chunk 2 wave + 1) ----
+    float ssum[2][8], ssq[2][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { ssum[0][c] = ssum[1][c] = 0.f; ssq[0][c] = ssq[1][c] = 0.f; }
+    auto stats_add = [&](int blk, const u32x4& piece) {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, piece);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float f = (float)x[c]; ssum[blk][c] += f; ssq[blk][c] += f * f; }
+    };
+    auto stats_flush = [&](int blk, int img) {            // reduce over the lanes that hold the same 8 channels, store, reset
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v[c] = ssum[blk][c]; v[8 + c] = ssq[blk][c]; ssum[blk][c] = 0.f; ssq[blk][c] = 0.f; }
+        if (VPS == 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += dpp_f<0x1B>(dpp_f<0x141>(v[i]));      // lane ^ 4
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += dpp_f<0x128>(v[i]);                        // lane ^ 8 (row rotate by 8)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 16, 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+        if (sp == 0 && chunk_live) {
+            float* dst = a.stats + (((long)img * 8 + 2 * wave + blk) * 2) * a.NS + n0 + sc8 * 8;
+            f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+            f32x4 q0 = {v[8], v[9], v[10], v[11]}, q1 = {v[12], v[13], v[14], v[15]};
+            *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
+            *reinterpret_cast<f32x4*>(dst + a.NS) = q0; *reinterpret_cast<f32x4*>(dst + a.NS + 4) = q1;
+        }
+    };
+    auto in_image = [&](int i) -> int { return i - a.g.div_tpi(i) * tpi; };   // position of iteration i's tile in its image
+
     // ---- the schedule (wreg_make_sched) ----
     constexpr int G = NSTEP * TN;
     constexpr int HDIST = (2 * G * 5) / 16;                // gaps between a halo vector's fetch and its LDS store
@@ -496,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     // An accumulator set is first read (first EA) at least four MFMAs after its last MFMA: hipcc pads no hazards for the
     // asm MFMAs.
     constexpr int G_MIN = 3;
-    constexpr auto SCH = wreg_make_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD>();
+    constexpr auto SCH = wreg_make_sched<G, TN, KS, NEPI, NI, NR, HV, HDIST, G_MIN, HAS_ADD, IN_SS, STATS>();
     static_assert(SCH.first_ea[0] >= 4 && SCH.first_ea[1] >= 4, "an accumulator set is read too soon after its last MFMA");
     static_assert(SCH.over == 0, "a side operation has no place in the schedule");
 
@@ -511,6 +569,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     unsigned out_cur0 = row_base(tpix, 0), out_cur1 = row_base(tpix, 1);      // (halo_tile was last called for the first tile)
     int next = nit > 1 ? tile_at(1) : tile;
     halo_tile(next);
+    if (IN_SS && nit > 0) load_in_ss(a.g.div_tpi(next));   // (the first tile's halo is in LDS, normalised, by now)
     int pix_next = tpix;
     unsigned out_prev1 = 0, voff_prev = OOB;               // block 1 of the previous tile (nothing to drain at first)
 #pragma nounroll
@@ -518,6 +577,12 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
         const int cur = it & 1;
         const unsigned char* hrow = smem + cur * HALO_BYTES + hrow0;
         WREG_STAMP(0);
+        // statistics: block 0 of THIS tile is drained during its block 1, block 1 of the PREVIOUS tile during this block 0
+        const int st_pos = STATS ? in_image(it) : 0;
+        const bool st_close0 = STATS && st_pos == tpi - 1;            // this tile closes its image
+        const bool st_close1 = STATS && it > 0 && st_pos == 0;        // the previous tile closed its image
+        const int st_img = STATS ? a.g.div_tpi(tile) : 0;             // (imo: tile_at(it) = this workgroup's tile `it`)
+        const int st_img_prev = STATS && it > 0 ? a.g.div_tpi(tile_at(it - 1)) : 0;
         unsigned out_next0 = 0, out_next1 = 0;
         // the state of the next iteration, computed in the middle of this one (scalar instructions between MFMAs)
         int nx_next = 0, nx_pix = 0, nx_y0 = 0, nx_x0 = 0;
@@ -579,7 +644,16 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
                         if (kind == W_ORD) wave_lds_order();
 #ifndef WREG_ABL_DRAIN
                         if (kind == W_DL) drain_load(ix);
-                        if (kind == W_DS) drain_store(u == 0 ? out_prev1 : out_cur0, u == 0 ? voff_prev : lane_off, ix);
+                        if (kind == W_DS) {
+                            drain_store(u == 0 ? out_prev1 : out_cur0, u == 0 ? voff_prev : lane_off, ix);
+                            if (STATS) {
+                                if (u == 1 || it > 0) stats_add(u == 0 ? 1 : 0, dpc[ix % 2]);
+                                if (ix == NI - 1) {
+                                    if (u == 1 && st_close0) stats_flush(0, st_img);
+                                    if (u == 0 && st_close1) stats_flush(1, st_img_prev);
+                                }
+                            }
+                        }
 #endif
                         if (kind == W_PARK) park_add(ix);
                     }
@@ -621,6 +695,7 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
         out_cur0 = out_next0; out_cur1 = out_next1;
         tile = next; next = nx_next; hbad = nx_hbad; horg = (unsigned)(nx_pix * CIN * 2);
         pix_next = nx_pix;
+        if (IN_SS) load_in_ss(a.g.div_tpi(next));          // for the halo stores of the next iteration (its tile after next)
     }
     WREG_RSTAMP(2);
     // ---- block 1 of the last tile is still in its accumulators (its residual rows are parked already) ----
@@ -630,7 +705,12 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
         for (int e = 0; e < NEPI; ++e) { epi_load(e); epi_a(acc1, e); if (has_add) epi_r(e); epi_b(e); epi_c(e); }
         wave_lds_order();
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { drain_load(i); drain_store(out_prev1, lane_off, i); }
+        for (int i = 0; i < NI; ++i) {
+            drain_load(i);
+            drain_store(out_prev1, lane_off, i);
+            if (STATS) stats_add(1, dpc[i % 2]);
+        }
+        if (STATS) stats_flush(1, a.g.div_tpi(tile_at(it - 1)));      // a workgroup's last tile closes an image
     }
     WREG_RSTAMP(3);
 }
@@ -649,9 +729,12 @@ static bool wreg_applicable(const GemmPlan& P) {
 
 static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                  const float* shift, const void* res, int relu, int accumulate, int out_f32, hipStream_t st,
-                                 unsigned long long* stamps = nullptr) {
+                                 unsigned long long* stamps = nullptr, const float* in_ss = nullptr, int in_relu = 0,
+                                 float* stats = nullptr) {
     // (ReLU before the addition of the old output is the one order this kernel does not have; nothing asks for it)
     if (out_f32 || !wreg_applicable(P) || (res && accumulate) || (relu && accumulate)) return false;
+    const bool feat = in_ss != nullptr || stats != nullptr;
+    if (feat && (res || accumulate)) return false;         // the feature instantiations carry no additive operand
     // Bit 31 of a lane's input offset is the "return zeros" marker and the tile origins are 32-bit byte offsets: tensors
     // stay below 2 GB less the descriptor's lead-in (16 384 images of 32 x 32 x 64 and more go to the LDS-weights kernel).
     if ((long)P.B * P.Hout * P.Wout * (P.CgS > P.NS ? P.CgS : P.NS) * 2 >= 0x80000000L - (long)(P.Wout + 1) * P.CgS * 2 - 16)
@@ -663,24 +746,30 @@ static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* 
     memset(&a, 0, sizeof(a));
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift;
     a.add = res ? res : (accumulate ? out : nullptr); a.add_after_relu = 0;
+    a.in_ss = in_ss; a.in_relu = in_relu; a.stats = stats;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.out_f32 = 0; a.stamps = stamps;
     make_tile_grid(P.Wout / 32, P.Hout / 8, 0, a.g);
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
     const int ntiles = P.B * a.g.tpi;
-    const int gx = ntiles < 256 ? ntiles : 256;            // persistent: one workgroup per CU
+    int gx = ntiles < 256 ? ntiles : 256;                  // persistent: one workgroup per CU
+    if (feat && gx > P.B) gx = P.B;                        // the feature variants walk whole images
     dim3 grid(gx, P.Npad / NT), block(256);
-#define WREG_CASE(C, N, A)                                                                               \
-    if (P.CgS == C && NT == N && (a.add != nullptr) == A) {                                              \
+    const bool f_in = in_ss != nullptr, f_st = stats != nullptr;
+#define WREG_CASE(C, N, A, FI, FS)                                                                       \
+    if (P.CgS == C && NT == N && (a.add != nullptr) == A && f_in == FI && f_st == FS) {                  \
         constexpr int lds = wreg_lds_bytes_of(C, N);                                                     \
         static LdsOptIn lds_opt;                                                                         \
-        lds_opt.ensure(reinterpret_cast<const void*>(&conv_wreg_bf16_kernel<C, N, wreg_lds_taps(C, N), A>), lds); \
-        hipLaunchKernelGGL((conv_wreg_bf16_kernel<C, N, wreg_lds_taps(C, N), A>), grid, block, lds, st, a); \
+        lds_opt.ensure(reinterpret_cast<const void*>(&conv_wreg_bf16_kernel<C, N, wreg_lds_taps(C, N), A, FI, FS>), lds); \
+        hipLaunchKernelGGL((conv_wreg_bf16_kernel<C, N, wreg_lds_taps(C, N), A, FI, FS>), grid, block, lds, st, a); \
         return true;                                                                                     \
     }
     // (64 input channels only: with 32 a block is 18 or 36 MFMAs, too short for its epilogue chain, and the halo kernel
     // measured faster)
-    WREG_CASE(64, 64, false) WREG_CASE(64, 32, false) WREG_CASE(64, 64, true) WREG_CASE(64, 32, true)
+    WREG_CASE(64, 64, false, false, false) WREG_CASE(64, 32, false, false, false)
+    WREG_CASE(64, 64, true, false, false) WREG_CASE(64, 32, true, false, false)
+    // the decoders' launches: 64 -> 64 leaving statistics, 64 -> 32 normalising its input and leaving statistics
+    WREG_CASE(64, 64, false, false, true) WREG_CASE(64, 32, false, true, true) WREG_CASE(64, 32, false, true, false)
 #undef WREG_CASE
     return false;
 }

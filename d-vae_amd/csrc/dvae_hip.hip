@@ -169,8 +169,9 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
                                "(see dvae_conv_supports_input_norm)");
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
-    if (g_opt_wreg.load() && !e.in_scale_shift && !e.out_stats &&
-        try_launch_wreg_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+    if (g_opt_wreg.load() &&
+        try_launch_wreg_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), nullptr, e.in_scale_shift,
+                             e.in_relu, e.out_stats)) {
         DVAE_CHECK_LAUNCH("conv_wreg");
         return DVAE_OK;
     }
