@@ -1,20 +1,22 @@
-// bf16 transposed-gather convolution with a whole (small) input image resident in LDS.
+// bf16 transposed-gather convolution with a 16x16 tile of the input (a whole image, for 16x16 maps) resident in LDS.
 //
 // ConvTranspose2d(k4, s2, p1) forward -- and the input-gradient of a stride-2 Conv2d -- decompose into output-parity
 // phases: phase (py, px) is a 2x2-tap unit-stride convolution of the 16x16 input that writes every other output
-// pixel.  All phases read the same input, so one workgroup keeps the whole 18x18 halo of one image (128 channels) in
+// pixel.  All phases read the same input, so one workgroup keeps the whole 18x18 halo of one tile (128 channels) in
 // LDS for all of them, and streams the weights through LDS one (phase, tap) slab of 64 x 128 at a time, double-buffered:
 // slabs are fetched into a register ring three steps ahead (an L2 round trip under load is longer than one step's
 // MFMAs) and written to the idle LDS buffer one step ahead, before the step's barrier.  The gather GEMM of igemm.hpp re-fetches the input rows once per tap and per phase through L2 and
 // synchronises twice per 64-deep K slab; here an image's input is read from HBM once and a barrier buys 16 MFMAs per wave.
 //
-// Persistent workgroups (one per CU, 8 waves) walk the images.  A wave owns 32 pixels of the 16x16 phase grid and all
+// Persistent workgroups (one per CU, 8 waves) walk the tiles: maps whose sides are multiples of 16 are cut into 16x16
+// tiles of the phase grid, a tile's halo comes from its neighbours (zeros outside the map).  A wave owns 32 pixels of the 16x16 phase grid and all
 // 64 output channels; the MFMA is issued as D[channel][pixel] = W * X^T, the finished phase is parked as bf16 in the
 // wave's private LDS patch and drained to HBM as whole 128-byte pixel rows from inside the next step's MFMA loop, where
 // the next image's halo is prefetched into registers as well.
 #pragma once
 #include <type_traits>
 
+#include "conv_halo.hpp"
 #include "igemm.hpp"
 
 namespace dvae {
@@ -28,6 +30,8 @@ struct ImageConvArgs {
     const void* res;         // residual, laid out like out, added before the ReLU, or NULL (FULL kernels)
     int relu;
     int B, Hout, Wout, N, NS, Ktot;
+    int Hin, Win;            // input map = phase grid, multiples of 16
+    TileGrid g;              // 16x16 tiles of the input map
     int nslab, DS;           // (phase, tap) slabs per image; output step of a phase grid step
     // per slab: halo offset of the tap (pixels), first K column in the packed rows, phase << 1 | last tap of its phase;
     // per phase: output offset.  Copied to LDS at kernel start: indexing kernel arguments with a run-time index costs a
@@ -93,32 +97,59 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     // ---- halo: HV vectors per thread, border pixels (outside the image) are zeros ----
     u32x4 hreg[HV];
     auto halo_pos = [&](int k, int& hp, int& cv) { const int v = tid + 512 * k; hp = v / VPP; cv = v % VPP; };
-    // byte offset of halo vector k inside an image (32 bits: the image base is uniform and stays in scalar registers)
+    // byte offset of halo vector k from the tile's halo corner (pixel (-1, -1) of the tile): 32 bits and never negative,
+    // the tile base is uniform and stays in scalar registers.  Bit k of m_top / m_bot / m_left / m_right: vector k sits
+    // in that border of the halo (outside the map when the tile touches that edge); m_tail: past the halo's end.
+    static_assert(512 % VPP == 0, "a thread's halo vectors all cover the same channels");
     unsigned hofs[HV];
+    unsigned m_top = 0u, m_bot = 0u, m_left = 0u, m_right = 0u, m_tail = 0u;
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
         int hp, cv;
         halo_pos(k, hp, cv);
-        const int iy = hp / HWD - 1, ix = hp % HWD - 1;
-        const bool ok = hp < HP && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
-        // border / tail vectors read pixel 0 of the image and are zeroed on the way to LDS: no branch around the load
-        const int py = ok ? iy : 0, px = ok ? ix : 0;
-        hofs[k] = (unsigned)((py * S + px) * CIN + cv * 8) * 2u;
+        const int hy = hp / HWD, hx = hp % HWD;
+        if (hp >= HP) m_tail |= 1u << k;
+        else {
+            if (hy == 0) m_top |= 1u << k;
+            if (hy == HWD - 1) m_bot |= 1u << k;
+            if (hx == 0) m_left |= 1u << k;
+            if (hx == HWD - 1) m_right |= 1u << k;
+        }
+        hofs[k] = (unsigned)((hy * a.Win + hx) * CIN + cv * 8) * 2u;
     }
-    auto load_halo_vec = [&](int b, int k) {
-        const unsigned char* ib = reinterpret_cast<const unsigned char*>(in + (long)b * (S * S * CIN));
-        hreg[k] = *reinterpret_cast<const u32x4*>(ib + hofs[k]);
+    // border / tail vectors read the tile's first pixel and are zeroed on the way to LDS: no branch around the load
+    const unsigned hsafe = (unsigned)((a.Win + 1) * CIN + (tid % VPP) * 8) * 2u;
+    // what a workgroup needs to know of a tile (all uniform but `bad`)
+    struct Tile {
+        const unsigned char* ib;   // the tile's halo corner in the input
+        long ob;                   // first output pixel (phase 0) of the tile, in pixels of the whole output tensor
+        unsigned bad;              // bit k: halo vector k of this thread is outside the map
+        unsigned img;              // image the tile belongs to
+        int pix0;                  // the tile's first pixel inside its image
     };
-    auto store_halo = [&]() {
+    auto tile_at = [&](int t) {
+        int img, ty, tx;
+        a.g.split(t, img, ty, tx);
+        Tile T;
+        T.img = (unsigned)img;
+        T.pix0 = (ty * a.Win + tx) * S;
+        T.ib = reinterpret_cast<const unsigned char*>(in + ((long)img * (a.Hin * a.Win) + T.pix0 - (a.Win + 1)) * CIN);
+        T.ob = (long)img * (a.Hout * a.Wout) + (long)(ty * a.Wout + tx) * (S * a.DS);
+        T.bad = m_tail | (ty == 0 ? m_top : 0u) | ((ty + 1) * S == a.Hin ? m_bot : 0u) | (tx == 0 ? m_left : 0u) |
+                ((tx + 1) * S == a.Win ? m_right : 0u);
+        return T;
+    };
+    auto load_halo_vec = [&](const Tile& T, int k) {
+        hreg[k] = *reinterpret_cast<const u32x4*>(T.ib + (((T.bad >> k) & 1u) ? hsafe : hofs[k]));
+    };
+    auto store_halo = [&](unsigned bad) {
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             int hp, cv;
             halo_pos(k, hp, cv);
             if (hp >= HP) continue;
-            const int iy = hp / HWD - 1, ix = hp % HWD - 1;
-            const bool ok = (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
             const u32x4 z = {0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(halo + hp * RS + cv * 16) = ok ? hreg[k] : z;
+            *reinterpret_cast<u32x4*>(halo + hp * RS + cv * 16) = ((bad >> k) & 1u) ? z : hreg[k];
         }
     };
     // ---- weight slab q = (phase, tap): NT rows of CIN, WV vectors per thread, ring slot q % RING ----
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
         }
     };
 
-    // wave w owns phase-grid pixels [32w, 32w + 32): rows 2w, 2w + 1; lane r is pixel 32w + r
+    // wave w owns the tile's phase-grid pixels [32w, 32w + 32): rows 2w, 2w + 1; lane r is pixel 32w + r
     const int gy = 2 * wave + (r >> 4), gx = r & 15;
     const unsigned char* hrow = halo + ((gy + 1) * HWD + gx + 1) * RS + 16 * h;
     const unsigned char* wrow = wbuf + r * RS + 16 * h;
@@ -168,10 +199,11 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
         d0[p] = __builtin_amdgcn_readfirstlane(tab[128 + p * 4]) * a.Wout + __builtin_amdgcn_readfirstlane(tab[128 + p * 4 + 1]);
         pn0[p] = FULL ? __builtin_amdgcn_readfirstlane(tab[128 + p * 4 + 2]) : 0;
     }
-    auto out_off = [&](int b, int p, int i) -> long {      // p, i: compile-time at every call site
-        if (ZF) return ((long)b * (S * S) + lpix[i]) * a.zL + 32 * p + sc8 * 8;
-        return ((long)b * (a.Hout * a.Wout) + d0[p] + lpix[i]) * a.NS + pn0[p] + sc8 * 8;
+    auto out_off = [&](long ob, int p, int i) -> long {    // ob: the tile's Tile::ob; p, i: compile-time at every call site
+        if (ZF) return (ob + lpix[i]) * a.zL + 32 * p + sc8 * 8;
+        return (ob + d0[p] + lpix[i]) * a.NS + pn0[p] + sc8 * 8;
     };
+    const int lanepix = gy * a.Win + gx;                   // this lane's pixel, relative to the tile's first
     const bf16* resb = reinterpret_cast<const bf16*>(a.res);
     u32x4 radd[NI];
     auto wave_lds_fence = [&]() {
@@ -181,23 +213,24 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
     };
     auto phase_of = [](int q) { return __builtin_popcount(LASTMASK & ((1u << q) - 1u)); };
 
-    const int G = gridDim.x;
-    int b = blockIdx.x;
-    if (b >= a.B) return;                                  // whole workgroup: grid <= B, never taken
+    const int G = gridDim.x, ntiles = a.B * a.g.tpi;
+    int b = blockIdx.x;                                    // tile
+    if (b >= ntiles) return;                               // whole workgroup: grid <= tiles, never taken
+    Tile cur = tile_at(b);
 #pragma unroll
-    for (int k = 0; k < HV; ++k) load_halo_vec(b, k);
+    for (int k = 0; k < HV; ++k) load_halo_vec(cur, k);
 #pragma unroll
     for (int i = 0; i < RING; ++i) load_slab(i, i % NSLAB);
     store_slab(0, 0);
-    bool have_prev = false;                                // an earlier image's last phase is parked in the patch
-    int pb = b;
+    bool have_prev = false;                                // an earlier tile's last phase is parked in the patch
+    long pob = cur.ob;
     int par = 0;                                           // LDS buffer of an image's slab 0 (alternates when NSLAB is odd)
     u32x4 dreg;
     f32x16 acc[TN];
-    for (; b < a.B; b += G) {
-        store_halo();
+    for (; b < ntiles; b += G) {
+        store_halo(cur.bad);
         __syncthreads();                                   // halo (and, first time, slab 0 and ssl) visible
-        const int nb = b + G < a.B ? b + G : b;            // next image, or this one again: the prefetch is unconditional
+        const Tile nxt = tile_at(b + G < ntiles ? b + G : b);   // next tile, or this one again: the prefetch is unconditional
 #pragma unroll
         for (int q = 0; q < NSLAB; ++q) {
             const int buf = (q & 1) ^ par;
@@ -221,7 +254,7 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
             // what is parked in the patch: the previous slab's phase if that slab ended one
             const bool drain_static = q > 0 && ((LASTMASK >> (q - 1)) & 1u);
             const int dp = q > 0 ? phase_of(q - 1) : phase_of(NSLAB - 1);
-            const int db = q > 0 ? b : pb;
+            const long dob = q > 0 ? cur.ob : pob;
             bf16x8 pv[2], wv[2][TN];
             pv[0] = *reinterpret_cast<const bf16x8*>(hp_);
 #pragma unroll
@@ -235,20 +268,20 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
                         wv[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(wp_ + j * 32 * RS + 32 * (s + 1));
                 }
                 if (s <= NI && (drain_static || (q == 0 && have_prev))) {   // drain slot s of NI + 1: patch -> HBM
-                    if (s > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(db, dp, s - 1)) = dreg;
+                    if (s > 0 && chunk_live) *reinterpret_cast<u32x4*>(outb + out_off(dob, dp, s - 1)) = dreg;
                     if (s < NI) dreg = *reinterpret_cast<const u32x4*>(stg + (s * PPI + sp) * SRS + sc8 * 16);
                 }
                 // the residual rows of a phase, in the second half of its last slab
                 if (FULL && last_tap && s >= KS - NI) {
                     const int i = s - (KS - NI);
                     const u32x4 z = {0u, 0u, 0u, 0u};
-                    radd[i] = a.res ? *reinterpret_cast<const u32x4*>(resb + out_off(b, phase_of(q), i)) : z;
+                    radd[i] = a.res ? *reinterpret_cast<const u32x4*>(resb + out_off(cur.ob, phase_of(q), i)) : z;
                 }
                 // the next image's halo: in the image's first two slabs, or (fused head: its epilogue wants the registers,
                 // and its slabs are long enough to cover the round trip) in the last two
                 constexpr int HQ = ZF ? NSLAB - 2 : 0;
-                if (q == HQ && s < HV) load_halo_vec(nb, s);
-                if (q == HQ + 1 && KS + s < HV) load_halo_vec(nb, KS + s);
+                if (q == HQ && s < HV) load_halo_vec(nxt, s);
+                if (q == HQ + 1 && KS + s < HV) load_halo_vec(nxt, KS + s);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[s & 1][j], pv[s & 1], acc[j], 0, 0, 0);
@@ -256,8 +289,8 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
             }
             if (last_tap && ZF) {
                 // ---- mu (acc[0]) and log_var (acc[1]) of 32 latent channels: draw eps, park z in the patch ----
-                const uint64_t img = a.zkey.index ? (uint64_t)a.zkey.index[b] : (uint64_t)(a.zkey.first + b);
-                unsigned e0 = (unsigned)(wave * 32 + r) * (unsigned)a.zL + 32u * q;   // first element of this lane pair's 32
+                const uint64_t img = a.zkey.index ? (uint64_t)a.zkey.index[cur.img] : (uint64_t)(a.zkey.first + cur.img);
+                unsigned e0 = (unsigned)(cur.pix0 + lanepix) * (unsigned)a.zL + 32u * q;   // first element of this lane pair's 32
                 // the counter does not depend on the image, so the first Philox round of every (slab, quad) is a loop
                 // invariant: hoisted, it would sit in 64 registers for the whole kernel
                 asm volatile("" : "+v"(e0));
@@ -331,13 +364,14 @@ __global__ __launch_bounds__(512) void conv_image_bf16_kernel(const ImageConvArg
             store_slab((q + 1) % RING, buf ^ 1);           // slab q + 1: that buffer was last read before the previous barrier
             __syncthreads();
         }
-        have_prev = true; pb = b;
+        have_prev = true; pob = cur.ob;
+        cur = nxt;
         if (NSLAB & 1) par ^= 1;
     }
-    if (chunk_live) {                                      // the last phase of the last image
+    if (chunk_live) {                                      // the last phase of the last tile
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            *reinterpret_cast<u32x4*>(outb + out_off(pb, phase_of(NSLAB - 1), i)) =
+            *reinterpret_cast<u32x4*>(outb + out_off(pob, phase_of(NSLAB - 1), i)) =
                 *reinterpret_cast<const u32x4*>(stg + (i * PPI + sp) * SRS + sc8 * 16);
     }
 }
@@ -353,16 +387,30 @@ static constexpr int image_zf_lds_bytes() {
     return 18 * 18 * (CIN * 2 + 16) + 2 * NT * (CIN * 2 + 16) + 64 * NSLAB * 4 + 8 * 32 * (NT + 16) + (32 * 4 + 4 * 4) * 4;
 }
 
-// Slab structure of a plan this kernel is built for: a transposed gather over 16x16 phase grids with 128 gathered and
-// <= 64 produced channels whose (slabs per image, last-tap mask) is one of the compiled pairs.  0 slabs: not applicable.
+// The input map of a plan cut into 16x16 tiles; false if its sides are not multiples of 16 or the tile index
+// arithmetic would not be exact for this batch.
+static bool image_tiles(const GemmPlan& P, ImageConvArgs& a) {
+    if (P.Hin < 16 || P.Win < 16 || P.Hin % 16 || P.Win % 16) return false;
+    a.Hin = P.Hin; a.Win = P.Win;
+    return make_tile_grid(P.Win / 16, P.Hin / 16, ((long)P.B + 1) * (P.Hin / 16) * (P.Win / 16), a.g);
+}
+static dim3 image_grid(const ImageConvArgs& a) {
+    const long nt = (long)a.B * a.g.tpi;
+    return dim3((unsigned)(nt < 256 ? nt : 256));
+}
+
+// Slab structure of a plan this kernel is built for: a transposed gather over phase grids of the input's size with 128
+// gathered and <= 64 produced channels whose (slabs per tile, last-tap mask) is one of the compiled pairs.  0 slabs: not
+// applicable.
 struct ImageGeom { int nslab; unsigned lastmask; };
 static ImageGeom image_geom(const GemmPlan& P) {
     const ImageGeom none = {0, 0u};
-    if (P.CgS != 128 || P.Npad != 64 || P.Hin != 16 || P.Win != 16 || P.nphase < 1) return none;
+    ImageConvArgs probe;
+    if (P.CgS != 128 || P.Npad != 64 || !image_tiles(P, probe) || P.nphase < 1) return none;
     ImageGeom g = {0, 0u};
     for (int i = 0; i < P.nphase; ++i) {
         const Phase& ph = P.ph[i];
-        if (ph.SY != 1 || ph.SX != 1 || ph.Hg != 16 || ph.Wg != 16 || ph.ntaps < 1) return none;
+        if (ph.SY != 1 || ph.SX != 1 || ph.Hg != P.Hin || ph.Wg != P.Win || ph.ntaps < 1) return none;
         if (ph.DSY != P.ph[0].DSY || ph.DSX != P.ph[0].DSY) return none;
         for (int t = 0; t < ph.ntaps; ++t)
             if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return none;
@@ -376,12 +424,13 @@ static ImageGeom image_geom(const GemmPlan& P) {
 }
 static bool image_applicable(const GemmPlan& P) { return image_geom(P).nslab != 0; }
 
-// 3x3 unit-stride conv 128 -> 128 over 16x16 maps (a residual block's convs in layer2): two blocks of 64 output
+// 3x3 unit-stride conv 128 -> 128 (a residual block's convs in layer2): two blocks of 64 output
 // channels x 9 taps = 18 slabs, with the scale / shift / residual / ReLU epilogue.
 static bool image_full_applicable(const GemmPlan& P) {
-    if (P.nphase != 1 || P.CgS != 128 || P.N != 128 || P.NS != 128 || P.Hin != 16 || P.Win != 16 || P.Hout != 16 || P.Wout != 16) return false;
+    ImageConvArgs probe;
+    if (P.nphase != 1 || P.CgS != 128 || P.N != 128 || P.NS != 128 || !image_tiles(P, probe) || P.Hout != P.Hin || P.Wout != P.Win) return false;
     const Phase& ph = P.ph[0];
-    if (ph.ntaps != 9 || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X || ph.Hg != 16 || ph.Wg != 16) return false;
+    if (ph.ntaps != 9 || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X || ph.Hg != P.Hin || ph.Wg != P.Win) return false;
     for (int t = 0; t < 9; ++t)
         if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return false;
     return true;
@@ -393,7 +442,8 @@ static bool try_launch_image_full(const GemmPlan& P, const void* in, const void*
     ImageConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.wp = wp; a.out = out; a.shift = shift; a.scale = scale; a.res = res; a.relu = relu;
-    a.B = P.B; a.Hout = 16; a.Wout = 16; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    a.B = P.B; a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    image_tiles(P, a);
     a.nslab = 18; a.DS = 1;
     const Phase& ph = P.ph[0];
     for (int half = 0; half < 2; ++half) {
@@ -409,7 +459,7 @@ static bool try_launch_image_full(const GemmPlan& P, const void* in, const void*
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsOptIn lds_opt;
     lds_opt.ensure(reinterpret_cast<const void*>(&conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>), lds);
-    dim3 grid(P.B < 256 ? P.B : 256), block(512);
+    dim3 grid = image_grid(a), block(512);
     hipLaunchKernelGGL((conv_image_bf16_kernel<128, 64, 18, 0x20100u, false, true>), grid, block, lds, st, a);
     return true;
 }
@@ -424,6 +474,7 @@ static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void*
     memset(&a, 0, sizeof(a));
     a.in = in; a.wp = wp; a.out = out; a.shift = shift; a.relu = relu;
     a.B = P.B; a.Hout = P.Hout; a.Wout = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
+    image_tiles(P, a);
     memset(a.slab_toff, 0, sizeof(a.slab_toff)); memset(a.slab_k0, 0, sizeof(a.slab_k0));
     memset(a.slab_phase, 0, sizeof(a.slab_phase)); memset(a.phase_d0y, 0, sizeof(a.phase_d0y)); memset(a.phase_d0x, 0, sizeof(a.phase_d0x));
     a.nslab = 0; a.DS = P.ph[0].DSY;
@@ -438,7 +489,7 @@ static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void*
     }
     constexpr int lds = image_lds_bytes<128, 64>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    dim3 grid(P.B < 256 ? P.B : 256), block(512);
+    dim3 grid = image_grid(a), block(512);
 #define IMAGE_CASE(NS_, MASK_)                                                                                      \
     if (g.nslab == NS_ && g.lastmask == MASK_) {                                                                    \
         static LdsOptIn lds_opt;                                                                                    \
@@ -451,9 +502,11 @@ static bool try_launch_image_bf16(const GemmPlan& P, const void* in, const void*
     return false;
 }
 
-// Fused encoder head on the image-resident kernel: 1x1 conv 128 -> 2 L over 16x16 maps, L = 32 * (4 or 8).
+// Fused encoder head on the tile-resident kernel: 1x1 conv 128 -> 2 L, L = 32 * (4 or 8).
 static bool image_zf_applicable(const GemmPlan& P, int L) {
-    if (P.nphase != 1 || P.CgS != 128 || P.Hin != 16 || P.Win != 16 || P.Hout != 16 || P.Wout != 16 || P.N != 2 * L) return false;
+    ImageConvArgs probe;
+    if (P.nphase != 1 || P.CgS != 128 || !image_tiles(P, probe) || P.Hout != P.Hin || P.Wout != P.Win || P.N != 2 * L) return false;
+    if ((long)P.Hin * P.Win * L >= (1l << 32)) return false;      // the noise element index inside an image is 32 bits
     const Phase& ph = P.ph[0];
     if (ph.ntaps != 1 || ph.dy[0] || ph.dx[0] || ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X) return false;
     return L == 128 || L == 256;
@@ -465,11 +518,12 @@ static bool try_launch_image_zf(const GemmPlan& P, const void* in, const void* w
     ImageConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.wp = wp; a.out = z; a.shift = bias; a.relu = 0;
-    a.B = P.B; a.Hout = 16; a.Wout = 16; a.N = L; a.NS = L; a.Ktot = P.Ktot;
+    a.B = P.B; a.Hout = P.Hout; a.Wout = P.Wout; a.N = L; a.NS = L; a.Ktot = P.Ktot;
+    image_tiles(P, a);
     a.nslab = L / 32; a.DS = 1;
     for (int q = 0; q < 16; ++q) a.slab_k0[q] = P.ph[0].koff + 32 * q * P.Ktot;   // slab q: weight rows 32 q .. of mu and of log_var
     a.zL = L; a.zkey = key;
-    dim3 grid(P.B < 256 ? P.B : 256), block(512);
+    dim3 grid = image_grid(a), block(512);
 #define IMAGE_ZF_CASE(NS_)                                                                                              \
     if (a.nslab == NS_) {                                                                                               \
         constexpr int lds = image_zf_lds_bytes<128, 64, NS_>();                                                         \

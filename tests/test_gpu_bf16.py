@@ -55,6 +55,14 @@ CONVS = [
     (256, 512, 3, 2, 1, False, 8, False),
     (512, 512, 3, 1, 1, False, 4, False),
     (256, 512, 1, 2, 0, False, 8, False),
+    # the tile-resident kernel on maps larger than one 16x16 tile (64x64 / 96x96 / 224x224 images): halos come from the
+    # neighbouring tiles, zeros only outside the map; 3 x 3 and 7 x 7 tile grids split the tile index by multiply-high
+    (128, 64, 4, 2, 1, True, 32, True),       # transposed conv, 16 slabs
+    (128, 64, 4, 2, 1, True, 48, True),
+    (128, 128, 3, 1, 1, False, 32, False),    # 18 slabs
+    (128, 128, 3, 1, 1, False, 112, False),
+    (64, 128, 3, 2, 1, False, 64, False),     # its input-gradient: 9 slabs over the 32x32 gradient map
+    (64, 128, 3, 2, 1, False, 96, False),
 ]
 
 
@@ -279,6 +287,9 @@ PERSISTENT = [
     (64, 64, 3, 1, 1, False, 96, "plain", 60),  # ... fewer images than workgroups: tiles strided over the grid
     (32, 3, 3, 1, 1, True, 96, "f32", 120),
     (3, 64, 3, 1, 1, False, 96, "plain", 120),
+    (128, 64, 4, 2, 1, True, 32, "plain", 300),   # tile-resident kernels: 4 tiles per image, 4.7 tiles per workgroup
+    (128, 128, 3, 1, 1, False, 48, "res", 150),   # ... 9 tiles per image
+    (128, 128, 3, 1, 1, False, 32, "res", 40),    # ... fewer tiles (160) than workgroups
 ]
 
 
@@ -338,6 +349,7 @@ BACKWARD = [
     (128, 64, 4, 2, 1, True, 16, 512),
     (128, 128, 3, 1, 1, False, 16, 512),
     (64, 64, 3, 1, 1, False, 96, 256),  # 36 tiles per image: not a power of two
+    (64, 128, 3, 2, 1, False, 64, 256), # tile-resident input-gradient over 32x32 gradient maps (4 tiles per image)
 ]
 
 
@@ -391,12 +403,13 @@ def test_backward_kernels_at_train_batch(cfg):
     assert rel_err(db.cpu(), sum(p_[1] for p_ in parts).cpu()) < 1e-4
 
 
-def test_fused_encoder_head_does_not_depend_on_the_batch():
-    """The fused head walks images with a persistent workgroup too, and its noise is keyed by the global image index
-    (resnet.py:2257-2259 draws per element): image i of an 800-image launch equals image i of a 3-image launch that
-    starts its numbering at i, bit for bit."""
+@pytest.mark.parametrize("h,B", [(16, 800), (32, 300), (48, 100)])
+def test_fused_encoder_head_does_not_depend_on_the_batch(h, B):
+    """The fused head walks images (16x16 tiles of larger maps) with a persistent workgroup too, and its noise is keyed
+    by the global image index and the element's place in the image (resnet.py:2257-2259 draws per element): image i of
+    a large launch equals image i of a 3-image launch that starts its numbering at i, bit for bit."""
     lib = L.lib()
-    cin, h, Ld, B, b = 128, 16, 256, 800, 3
+    cin, Ld, b = 128, 256, 3
     g = torch.Generator().manual_seed(23)
     w = torch.randn(2 * Ld, cin, 1, 1, generator=g) / cin ** 0.5
     bias = (0.1 * torch.randn(2 * Ld, generator=g)).cuda()
@@ -415,16 +428,17 @@ def test_fused_encoder_head_does_not_depend_on_the_batch():
 
     big = run(0, B)
     assert torch.isfinite(big.float()).all()
-    for lo in (0, 511, B - b):
+    for lo in (0, B // 2 + 11, B - b):
         assert torch.equal(big[lo:lo + b], run(lo, b)), f"images {lo}..{lo + b - 1} differ"
 
 
 @pytest.mark.parametrize("B,Ld,h,stream_id", [(3, 256, 16, 5), (5, 128, 16, 5), (3, 256, 16, 0x80000005), (5, 128, 16, 0x80000005),
-                                              (3, 256, 32, 0x80000005), (2, 256, 24, 5)])
+                                              (3, 256, 32, 0x80000005), (2, 256, 24, 5), (3, 128, 32, 5), (2, 256, 48, 0x80000005),
+                                              (2, 128, 112, 5)])
 def test_fused_encoder_head_bf16(B, Ld, h, stream_id):
     """fc_mu|fc_var (1x1 conv, resnet.py:2245-2246) + reparameterise (resnet.py:2257-2259) in one launch against
     torch fp32 on the same bf16-rounded operands and the same Philox noise; only the stored z is rounded to bf16.
-    16 x 16 maps run on the image-resident kernel, other sizes on the gather GEMM; stream ids with bit 31 draw eight
+    Maps whose sides are multiples of 16 run on the tile-resident kernel, other sizes on the gather GEMM; stream ids with bit 31 draw eight
     normals per Philox call (the two lane halves of a pixel trade halves of each group): the in-kernel draw must equal what
     dvae_philox_normal materialises for the same key."""
     lib = L.lib()
@@ -458,6 +472,64 @@ def test_fused_encoder_head_bf16(B, Ld, h, stream_id):
     L.check(lib.dvae_fc_reparam_fwd_philox(xa.data_ptr(), pk.data_ptr(), bdev.data_ptr(), z.data_ptr(), C.byref(d), Ld,
                                            None, 40000, seed, stream_id, L.BF16, st))
     assert rel_err(from_act(z, Ld), z_ref) < 6e-3
+
+
+@pytest.mark.parametrize("H,W", [(32, 48), (48, 16), (16, 80)])
+def test_tile_resident_kernels_on_non_square_maps(H, W):
+    """The three flavours of the tile-resident kernel (transposed conv, 3x3 128 -> 128 with the residual epilogue, fused
+    encoder head) on H x W maps with H != W: rows and columns of the tile grid must not be confused anywhere."""
+    lib = L.lib()
+    B, cin = 3, 128
+    g = torch.Generator().manual_seed(H * 100 + W)
+    q = lambda t: t.bfloat16().float()      # noqa: E731
+    st = L.stream()
+    x = q(torch.randn(B, cin, H, W, generator=g))
+    xa = to_act(x, L.BF16)
+
+    def packed(d, w, op=L.OP_FWD):
+        pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), op), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), op, L.BF16, st))
+        return pk
+
+    # ConvTranspose2d(128, 64, 4, 2, 1) + bias + ReLU
+    w = q(torch.randn(cin, 64, 4, 4, generator=g) / (cin * 4) ** 0.5)
+    bias = torch.randn(64, generator=g)
+    d = L.ConvDesc(B, H, W, cin, 64, 4, 4, 2, 1, 1)
+    y = torch.full((B, 2 * H, 2 * W, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    bd = bias.cuda()
+    ep = L.Epilogue(None, bd.data_ptr(), None, 1, 0)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), packed(d, w).data_ptr(), C.byref(ep), y.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(y, 64), F.relu(F.conv_transpose2d(x, w, bias, stride=2, padding=1))) < 6e-3
+    # Conv2d(128, 128, 3, 1, 1) * scale + shift + residual, ReLU
+    w = q(torch.randn(128, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    res = q(torch.randn(B, 128, H, W, generator=g))
+    d = L.ConvDesc(B, H, W, cin, 128, 3, 3, 1, 1, 0)
+    y = torch.full((B, H, W, 128), 7.0, device="cuda", dtype=torch.bfloat16)
+    scd, shd, resa = sc.cuda(), sh.cuda(), to_act(res, L.BF16)
+    ep = L.Epilogue(scd.data_ptr(), shd.data_ptr(), resa.data_ptr(), 1, 0)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), packed(d, w).data_ptr(), C.byref(ep), y.data_ptr(), C.byref(d), L.BF16, st))
+    ref = F.relu(q(F.conv2d(x, w, None, 1, 1) * sc[None, :, None, None] + sh[None, :, None, None]) + res)
+    assert rel_err(from_act(y, 128), ref) < 6e-3
+    # input-gradient of Conv2d(64, 128, 3, 2, 1) from an H x W gradient map
+    w = q(torch.randn(128, 64, 3, 3, generator=g) / 24)
+    d = L.ConvDesc(B, 2 * H, 2 * W, 64, 128, 3, 3, 2, 1, 0)
+    dx = torch.full((B, 2 * H, 2 * W, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_dgrad(xa.data_ptr(), packed(d, w, L.OP_DGRAD).data_ptr(), dx.data_ptr(), 0, C.byref(d), L.BF16, st))
+    assert rel_err(from_act(dx, 64), F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)) < 6e-3
+    # fused encoder head
+    Ld, seed, stream_id = 128, 99, 0x80000003
+    w = q(torch.randn(2 * Ld, cin, 1, 1, generator=g) / cin ** 0.5)
+    bias = (0.1 * torch.randn(2 * Ld, generator=g))
+    mulv = F.conv2d(x, w, bias)
+    d = L.ConvDesc(B, H, W, cin, 2 * Ld, 1, 1, 1, 0, 0)
+    eps = torch.empty(B, H, W, Ld, device="cuda")
+    L.check(lib.dvae_philox_normal(eps.data_ptr(), None, 500, B, H * W * Ld, seed, stream_id, st))
+    z = torch.full((B, H, W, Ld), 7.0, device="cuda", dtype=torch.bfloat16)
+    bd = bias.cuda()
+    L.check(lib.dvae_fc_reparam_fwd_philox(xa.data_ptr(), packed(d, w).data_ptr(), bd.data_ptr(), z.data_ptr(), C.byref(d), Ld,
+                                           None, 500, seed, stream_id, L.BF16, st))
+    assert rel_err(from_act(z, Ld), eps.cpu().permute(0, 3, 1, 2) * torch.exp(0.5 * mulv[:, Ld:]) + mulv[:, :Ld]) < 6e-3
 
 
 @pytest.mark.parametrize("cin,cout,hin,tr,B", [(64, 64, 32, True, 5), (64, 32, 32, True, 5), (32, 64, 64, False, 5),
