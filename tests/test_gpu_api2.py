@@ -102,6 +102,10 @@ def test_bf16_trainers_through_api_match_f32(tmp_path):
         if trained is None:
             trained = {k: v.detach().clone() for k, v in m.state_dict().items()}
         m2 = make_model(trained)
+        # bf16 engines draw their purification noise from the 16-bit-uniform Philox stream; the fp32 engine is built here,
+        # at the pass's batch size, and switched to that stream so that both legs see the same eps
+        m2.act_dtype = dt
+        m2._engine_for(torch.empty(256, 3, 32, 32, device="cuda")).inference_noise16 = True
         t = Trainer(torch.nn.CrossEntropyLoss(), loaders, None, Cfg(), datasets_generator=gen, exp_name=str(tmp_path / dt),
                     iters=1, purify_batch=256, seed=9, act_dtype=dt)
         t.train(0, None, m2, None, None, None)
