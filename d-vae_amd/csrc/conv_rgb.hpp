@@ -1,0 +1,196 @@
+// 3x3 unit-stride bf16 convolution from 32 stored channels to at most 4 output channels, fp32 output, on 32-pixel-wide
+// images: the decoders' last layer (32 -> RGB).  HBM-bound: 64 B read and 16 B written per pixel against 1.7 kFLOP.
+//
+// With three output channels a 32x32 MFMA tile is 29/32 padding and the pixel operand of every tap is a separate LDS
+// read.  Here the horizontal taps ride in the output rows of a v_mfma_f32_16x16x32_bf16 instead: row m = 4 dx + o of
+// the weight operand holds W[dy][dx][o][0..31] (K = the 32 input channels of ONE pixel), the pixel operand is 16
+// consecutive pixels of image row y + dy, and the three dy steps accumulate into
+//     D[4 dx + o][q] = sum_dy sum_c W[dy][dx][o][c] x[y + dy][q][c] ,
+// three MFMAs and three 16-byte LDS reads per 16 pixels.  The output is out[y][x][o] = D[o][x-1] + D[4+o][x] + D[8+o][x+1]:
+// a lane holds the four o of one (dx, q) as its accumulator quad, parks it in the wave's LDS patch and reads the three
+// shifted quads of its output pixel back.  Columns -1 and 32 are the zero padding of a 32-wide image, so a tile needs no
+// halo columns: its ten input rows are one contiguous span of memory.
+//
+// A workgroup (4 waves) owns tiles of 8 output rows; a wave two of them.  Persistent over tiles with the next tile's
+// rows fetched into registers before the current one is computed; the optional per-(image, channel) scale / shift
+// (+ ReLU) of the producer's InstanceNorm is applied between registers and LDS (padding rows stay zero).  33 KB of LDS:
+// four workgroups per CU keep ~80 KB of loads in flight per CU.
+#pragma once
+#include "igemm.hpp"
+
+namespace dvae {
+
+struct RgbArgs {
+    const void* in;          // bf16 [B][H][32][32]
+    const void* wp;          // packed forward weights [Npad][Ktot], K = (tap, channel)
+    float* out;              // fp32 [B][H][32][4]
+    const float* scale;      // per output channel, or null (1)
+    const float* shift;      // per output channel, or null (0)
+    const float* in_ss;      // optional input normalisation [B][2][32]: x <- relu?(x * scale + shift) while staging
+    int in_relu;
+    int B, H, N, Ktot;
+    int tap[3][3];           // packed tap index of offset (dy - 1, dx - 1)
+};
+
+static constexpr int RGB_HALO_BYTES = 10 * 32 * 64;            // ten rows of 32 pixels x 32 bf16 channels
+static constexpr int RGB_PLANE = 34 * 16;                      // one dx plane of one output row: columns -1 .. 32, f32x4 each
+static constexpr int RGB_PATCH_BYTES = 2 * 3 * RGB_PLANE;      // per wave: two output rows
+static constexpr int RGB_LDS_BYTES = RGB_HALO_BYTES + 4 * RGB_PATCH_BYTES;
+
+__global__ __launch_bounds__(256, 4) void conv_rgb_bf16_kernel(const RgbArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RGB_LDS_BYTES];
+    unsigned char* halo = smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned char* patch = smem + RGB_HALO_BYTES + wave * RGB_PATCH_BYTES;
+    const bf16* in = reinterpret_cast<const bf16*>(a.in);
+    const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
+    const int tpi = a.H >> 3, ntiles = a.B * tpi;
+
+    // ---- weight operand of the three dy steps: lane (m = lane & 15, kg = lane >> 4) holds W[dy][m >> 2][m & 3][8 kg ..]
+    const int q = lane & 15, kg = lane >> 4;
+    bf16x8 wa[3];
+    {
+        const int dxi = q >> 2, o = q & 3;
+        const bool live = dxi < 3 && o < a.N;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (live) w = *reinterpret_cast<const u32x4*>(wp + (long)o * a.Ktot + a.tap[d][dxi] * 32 + kg * 8);
+            wa[d] = *reinterpret_cast<bf16x8*>(&w);
+        }
+    }
+    f32x4 esc, esh;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        esc[o] = o < a.N ? (a.scale ? a.scale[o] : 1.f) : 0.f;
+        esh[o] = (o < a.N && a.shift) ? a.shift[o] : 0.f;
+    }
+    // the patch's edge columns are read as the zero padding of the dx = -1 / +1 planes and never written
+    for (int i = tid; i < 4 * RGB_PATCH_BYTES / 16; i += 256)
+        *reinterpret_cast<u32x4*>(smem + RGB_HALO_BYTES + i * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- staging: vector v = tid + 256 k of the ten rows (128 vectors per row): row 2k + (tid >> 7), pixel column
+    // (tid & 127) >> 2, 8-channel chunk tid & 3.  In LDS the four chunks of a pixel are permuted by a function of the
+    // column so that the 16 lanes a ds_read_b128 serves together ({0-3, 12-15, 20-27}, ...) fall on 16 different
+    // 16-byte slots of the 256-byte bank row: chunk ^ {0, 2, 3, 1}[(column >> 2) & 3].
+    const int scol = (tid & 127) >> 2, schunk = tid & 3, srow0 = tid >> 7;
+    const int sw_st = (schunk ^ ((0x1320 >> (((scol >> 2) & 3) * 4)) & 3)) * 16;
+    unsigned char* sdst = halo + (srow0 * 32 + scol) * 64 + sw_st;
+    u32x4 hreg[5];
+    unsigned live = 0;                                            // bit k: hreg[k] is a row inside the image
+    f32x4 isc[2], ish[2];
+    auto load_tile = [&](int tile) {
+        const int b = tile / tpi, y0 = (tile - b * tpi) * 8;
+        // every load is unconditional (a load inside a branch is waited for where the branch ends): rows outside the
+        // image re-read an edge row and are zeroed on their way to LDS; without a normalisation the scale / shift
+        // registers are filled from the input tensor and never used
+        const float* p = a.in_ss ? a.in_ss + (long)b * 64 + schunk * 8 : reinterpret_cast<const float*>(a.in);
+        isc[0] = *reinterpret_cast<const f32x4*>(p); isc[1] = *reinterpret_cast<const f32x4*>(p + 4);
+        ish[0] = *reinterpret_cast<const f32x4*>(p + 32); ish[1] = *reinterpret_cast<const f32x4*>(p + 36);
+        const bf16* src = in + (long)b * a.H * (32 * 32) + scol * 32 + schunk * 8;
+        live = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int iy = y0 - 1 + 2 * k + srow0;
+            const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+            hreg[k] = *reinterpret_cast<const u32x4*>(src + cy * (32 * 32));
+            if (iy == cy) live |= 1u << k;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            u32x4 v = hreg[k];
+            if (!(live >> k & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+            else if (a.in_ss) {
+                bf16x8 x = *reinterpret_cast<bf16x8*>(&v);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float f = (float)x[c] * isc[c >> 2][c & 3] + ish[c >> 2][c & 3];
+                    if (a.in_relu) f = fmaxf(f, 0.f);
+                    x[c] = (bf16)f;
+                }
+                v = *reinterpret_cast<u32x4*>(&x);
+            }
+            *reinterpret_cast<u32x4*>(sdst + k * (2 * 32 * 64)) = v;
+        }
+    };
+
+    // ---- MFMA side: pixel operand of (halo row, 16-pixel group g): lane (q, kg) reads chunk kg of pixel 16 g + q
+    const unsigned char* frd = halo + q * 64 + ((kg ^ ((0x1320 >> ((q >> 2) * 4)) & 3)) * 16);
+    // combine side: lane = (output row rr of the wave's two, column x)
+    const int rr = lane >> 5, x = lane & 31;
+    auto wave_lds_fence = [&]() {                          // LDS hand-over between lanes of one wave: order, no barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        store_tile();
+        __syncthreads();                                   // the tile's rows (first time: the zeroed patches) are visible
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);                // in flight under the MFMAs and the combine
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const bf16x8 pv = *reinterpret_cast<const bf16x8*>(frd + ((2 * wave + r2 + d) * 32 + 16 * g) * 64);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[d], pv, acc, 0, 0, 0);
+                }
+                if (kg < 3) *reinterpret_cast<f32x4*>(patch + (r2 * 3 + kg) * RGB_PLANE + (16 * g + q + 1) * 16) = acc;
+            }
+        }
+        wave_lds_fence();
+        {
+            const unsigned char* pr = patch + rr * 3 * RGB_PLANE + x * 16;
+            const f32x4 l = *reinterpret_cast<const f32x4*>(pr);                          // dx = -1: D[o][x - 1]
+            const f32x4 c = *reinterpret_cast<const f32x4*>(pr + RGB_PLANE + 16);         // dx =  0: D[4 + o][x]
+            const f32x4 r = *reinterpret_cast<const f32x4*>(pr + 2 * RGB_PLANE + 32);     // dx = +1: D[8 + o][x + 1]
+            f32x4 o4;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o4[o] = ((l[o] + c[o]) + r[o]) * esc[o] + esh[o];
+            const int b = tile / tpi, y0 = (tile - b * tpi) * 8;
+            *reinterpret_cast<f32x4*>(a.out + (((long)b * a.H + y0 + 2 * wave + rr) * 32 + x) * 4) = o4;
+        }
+        __syncthreads();                                   // every wave is done with these rows (and with its patch)
+    }
+}
+
+// true if the plan is a launch of the kernel above
+static bool rgb_applicable(const GemmPlan& P, int out_f32) {
+    if (!out_f32 || P.nphase != 1 || P.CgS != 32 || P.N > 4) return false;
+    const Phase& ph = P.ph[0];
+    if (ph.SY != 1 || ph.SX != 1 || ph.DSY != 1 || ph.DSX != 1 || ph.D0Y || ph.D0X || ph.ntaps != 9) return false;
+    if (P.Hin != P.Hout || P.Win != P.Wout || ph.Hg != P.Hout || ph.Wg != P.Wout) return false;
+    if (P.Wout != 32 || P.Hout % 8 || (long)P.B * (P.Hout / 8) > 0x7fffffffL) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return false;
+        seen |= 1u << ((ph.dy[t] + 1) * 3 + ph.dx[t] + 1);
+    }
+    return seen == 0x1ffu;
+}
+
+static bool try_launch_rgb_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
+                                const float* shift, const void* res, int relu, int accumulate, int out_f32, hipStream_t st,
+                                const float* in_ss, int in_relu, const float* out_stats) {
+    if (res || relu || accumulate || out_stats || !rgb_applicable(P, out_f32)) return false;
+    const Phase& ph = P.ph[0];
+    RgbArgs a;
+    a.in = in; a.wp = wp; a.out = reinterpret_cast<float*>(out); a.scale = scale; a.shift = shift;
+    a.in_ss = in_ss; a.in_relu = in_relu;
+    a.B = P.B; a.H = P.Hout; a.N = P.N; a.Ktot = P.Ktot;
+    for (int t = 0; t < 9; ++t) a.tap[ph.dy[t] + 1][ph.dx[t] + 1] = t;
+    const int ntiles = P.B * (P.Hout / 8);
+    const int gx = ntiles < 256 * 4 ? ntiles : 256 * 4;
+    hipLaunchKernelGGL(conv_rgb_bf16_kernel, dim3(gx), dim3(256), 0, st, a);
+    return true;
+}
+
+}  // namespace dvae

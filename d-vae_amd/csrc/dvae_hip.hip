@@ -10,6 +10,7 @@
 #include "wgrad_big.hpp"
 #include "conv_stem.hpp"
 #include "conv_point.hpp"
+#include "conv_rgb.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -46,6 +47,7 @@ static float* static_scratch_for_current_device() {
 
 // diagnostic switches (dvae_set_option): which of two equivalent kernels serves a launch
 static std::atomic<int> g_opt_wreg{1};
+static std::atomic<int> g_opt_rgb{1};
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
@@ -72,6 +74,7 @@ const char* dvae_version(void) { return "dvae_hip 0.2 (gfx950)"; }
 int dvae_set_option(const char* name, int value) {
     if (!name) DVAE_FAIL(DVAE_EINVAL, "set_option: null name");
     if (!strcmp(name, "conv_wreg")) { g_opt_wreg.store(value != 0); return DVAE_OK; }
+    if (!strcmp(name, "conv_rgb")) { g_opt_rgb.store(value != 0); return DVAE_OK; }
     DVAE_FAIL(DVAE_EINVAL, "set_option: unknown option '%s'", name);
 }
 const char* dvae_last_error(void) { return g_err; }
@@ -169,6 +172,12 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
                                "(see dvae_conv_supports_input_norm)");
     if (dtype == DVAE_F32)
         return launch_igemm<float>(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, 1, S(st));
+    if (g_opt_rgb.load() &&
+        try_launch_rgb_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), e.in_scale_shift, e.in_relu,
+                            e.out_stats)) {
+        DVAE_CHECK_LAUNCH("conv_rgb");
+        return DVAE_OK;
+    }
     if (g_opt_wreg.load() &&
         try_launch_wreg_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), nullptr, e.in_scale_shift,
                              e.in_relu, e.out_stats)) {
