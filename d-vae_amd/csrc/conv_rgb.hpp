@@ -97,20 +97,27 @@ __global__ __launch_bounds__(256, 4) void conv_rgb_bf16_kernel(const RgbArgs a) 
             if (iy == cy) live |= 1u << k;
         }
     };
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef short i16x2_t __attribute__((ext_vector_type(2)));
+    const i16x2_t in_lo16 = {(short)(a.in_relu ? 0 : -32768), (short)(a.in_relu ? 0 : -32768)};
     auto store_tile = [&]() {
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             u32x4 v = hreg[k];
             if (!(live >> k & 1u)) v = u32x4{0u, 0u, 0u, 0u};
             else if (a.in_ss) {
-                bf16x8 x = *reinterpret_cast<bf16x8*>(&v);
+                // per pair of channels: two unpacks, a packed fma, a packed conversion, a packed integer max (ReLU on the
+                // rounded pair: a bf16 read as a signed 16-bit integer is negative exactly when the number is)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float f = (float)x[c] * isc[c >> 2][c & 3] + ish[c >> 2][c & 3];
-                    if (a.in_relu) f = fmaxf(f, 0.f);
-                    x[c] = (bf16)f;
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned u = v[c];
+                    const f32x2_t x = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+                    const f32x2_t sc = {isc[c >> 1][2 * (c & 1)], isc[c >> 1][2 * (c & 1) + 1]};
+                    const f32x2_t sh = {ish[c >> 1][2 * (c & 1)], ish[c >> 1][2 * (c & 1) + 1]};
+                    const bf16x2_t o = __builtin_convertvector(__builtin_elementwise_fma(x, sc, sh), bf16x2_t);
+                    v[c] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, o), in_lo16));
                 }
-                v = *reinterpret_cast<u32x4*>(&x);
             }
             *reinterpret_cast<u32x4*>(sdst + k * (2 * 32 * 64)) = v;
         }
