@@ -11,6 +11,7 @@
 #include "conv_stem.hpp"
 #include "conv_point.hpp"
 #include "conv_rgb.hpp"
+#include "conv_down.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -48,6 +49,7 @@ static float* static_scratch_for_current_device() {
 // diagnostic switches (dvae_set_option): which of two equivalent kernels serves a launch
 static std::atomic<int> g_opt_wreg{1};
 static std::atomic<int> g_opt_rgb{1};
+static std::atomic<int> g_opt_down{1};
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
@@ -75,6 +77,7 @@ int dvae_set_option(const char* name, int value) {
     if (!name) DVAE_FAIL(DVAE_EINVAL, "set_option: null name");
     if (!strcmp(name, "conv_wreg")) { g_opt_wreg.store(value != 0); return DVAE_OK; }
     if (!strcmp(name, "conv_rgb")) { g_opt_rgb.store(value != 0); return DVAE_OK; }
+    if (!strcmp(name, "conv_down")) { g_opt_down.store(value != 0); return DVAE_OK; }
     DVAE_FAIL(DVAE_EINVAL, "set_option: unknown option '%s'", name);
 }
 const char* dvae_last_error(void) { return g_err; }
@@ -191,6 +194,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     }
     if (e.in_scale_shift || e.out_stats)                  // the gather GEMM has neither: never drop them silently
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation / output statistics unavailable for this launch");
+    if (g_opt_down.load() && try_launch_down_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_down");
+        return DVAE_OK;
+    }
     if (try_launch_image_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
         DVAE_CHECK_LAUNCH("conv_image");
         return DVAE_OK;

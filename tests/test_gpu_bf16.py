@@ -290,7 +290,42 @@ PERSISTENT = [
     (128, 64, 4, 2, 1, True, 32, "plain", 300),   # tile-resident kernels: 4 tiles per image, 4.7 tiles per workgroup
     (128, 128, 3, 1, 1, False, 48, "res", 150),   # ... 9 tiles per image
     (128, 128, 3, 1, 1, False, 32, "res", 40),    # ... fewer tiles (160) than workgroups
+    (64, 128, 3, 2, 1, False, 32, "plain"),       # stride-2 weights-in-registers kernel: 12.5 tiles per workgroup
+    (64, 128, 3, 2, 1, False, 32, "bnrelu", 50),  # ... one tile per workgroup, scale / shift / ReLU
+    (64, 128, 3, 2, 1, False, 96, "bnrelu", 130), # ... 36 tiles per image
+    (32, 3, 3, 1, 1, True, 32, "f32", 50),        # decoder head kernel: fewer tiles than workgroups
 ]
+
+
+@pytest.mark.parametrize("hin,B", [(32, 5), (64, 3)])
+def test_down_conv_epilogue(hin, B):
+    """The stride-2 3x3 conv 64 -> 128 (resnet.py:26-31 with stride 2: layer2's first conv) with the folded BatchNorm + ReLU
+    epilogue of the inference path, against torch on the bf16-rounded operands: <= 6e-3 of scale (one bf16 rounding)."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    q = lambda t: t.bfloat16().float()      # noqa: E731
+    w = q(torch.randn(128, 64, 3, 3, generator=g) / 24.0)
+    x = q(torch.randn(B, 64, hin, hin, generator=g))
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    want = torch.relu(F.conv2d(x, w, None, stride=2, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    d = L.ConvDesc(B, hin, hin, 64, 128, 3, 3, 2, 1, 0)
+    st = L.stream()
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    ya = torch.full((B, hin // 2, hin // 2, 128), 7.0, device="cuda", dtype=torch.bfloat16)
+    scd, shd = sc.cuda(), sh.cuda()
+    ep = L.Epilogue(scd.data_ptr(), shd.data_ptr(), None, 1, 0)
+    L.check(lib.dvae_conv_fwd(to_act(x, L.BF16).data_ptr(), pk.data_ptr(), C.byref(ep), ya.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(ya, 128), want) < 6e-3
+    # the gather GEMM on the same launch (the dedicated kernel switched off) rounds the same fp32 sums: equal up to the
+    # order of summation
+    yb = torch.full_like(ya, 7.0)
+    L.check(lib.dvae_set_option(b"conv_down", 0))
+    try:
+        L.check(lib.dvae_conv_fwd(to_act(x, L.BF16).data_ptr(), pk.data_ptr(), C.byref(ep), yb.data_ptr(), C.byref(d), L.BF16, st))
+    finally:
+        L.check(lib.dvae_set_option(b"conv_down", 1))
+    assert rel_err(ya.float().cpu(), yb.float().cpu()) < 4e-3
 
 
 @pytest.mark.parametrize("cfg", PERSISTENT, ids=lambda c: "-".join(str(v) for v in c))
@@ -313,7 +348,7 @@ def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
     if cs_in > cin:
         x[..., cin:] = 0
     res = torch.randn(B, ho, ho, cs_out, generator=g).cuda().bfloat16() if mode == "res" else None
-    sc = (torch.rand(cout, generator=g) + 0.5).cuda() if mode == "res" else None
+    sc = (torch.rand(cout, generator=g) + 0.5).cuda() if mode in ("res", "bnrelu") else None
     sh = torch.randn(cout, generator=g).cuda()
     st = L.stream()
     odt = torch.float32 if f32out else torch.bfloat16
@@ -323,7 +358,8 @@ def test_persistent_kernels_do_not_depend_on_the_batch(cfg):
         pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
         L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
         y = torch.full((n, ho, ho, cs_out), 3.0, device="cuda", dtype=odt)
-        ep = L.Epilogue(L.ptr(sc), sh.data_ptr(), None if res is None else res[lo:lo + n].data_ptr(), int(mode == "res"), int(f32out))
+        ep = L.Epilogue(L.ptr(sc), sh.data_ptr(), None if res is None else res[lo:lo + n].data_ptr(), int(mode in ("res", "bnrelu")),
+                        int(f32out))
         L.check(lib.dvae_conv_fwd(x[lo:lo + n].data_ptr(), pk.data_ptr(), C.byref(ep), y.data_ptr(), C.byref(d), L.BF16, st))
         torch.cuda.synchronize()
         return y
