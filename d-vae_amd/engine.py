@@ -754,16 +754,20 @@ class DVAEEngine:
             d_mulv.add_(d_mulv_extra)
         stem_out = L_["stem_out"]
         self._wgrad("fc", stem_out, d_mulv, b)
-        split = allreduce is not None and self._batch_reduce and self._overlap
+        # The slabs of the latent convs and the decoders are reduced as soon as the last of them is there, on the side
+        # stream under the stem's backward: only the stem's own slabs are left for the reduction at the end.
+        split = self._batch_reduce and self._overlap and getattr(self, "_split_reduce", True)
         if split:
             # everything behind early_offset is final once the side stream gets here (emb_bwd ran on the main stream
             # before the fc weight gradient was issued, and _wgrad made the side stream wait for that point)
-            side, comm = self._side_stream(), self._comm_stream()
+            side = self._side_stream()
             with torch.cuda.stream(side):
                 self._wgrad_reduce_all(b, "early")
-            comm.wait_stream(side)                           # a stream of its own: the stem's weight gradients, which
-            with torch.cuda.stream(comm):                    # follow on the side stream, do not queue behind the collective
-                allreduce(self.G[self.early_offset:])
+            if allreduce is not None:
+                comm = self._comm_stream()
+                comm.wait_stream(side)                       # a stream of its own: the stem's weight gradients, which
+                with torch.cuda.stream(comm):                # follow on the side stream, do not queue behind the collective
+                    allreduce(self.G[self.early_offset:])
         if cfg.sample_wise and cfg.use_y:
             d_stem = d_ep
             self._dgrad("fc", d_mulv, d_stem, b, accumulate=True)
@@ -791,8 +795,8 @@ class DVAEEngine:
             torch.cuda.current_stream().wait_stream(self._side_stream())
         if allreduce is not None:
             allreduce(self.G[:self.early_offset] if split else self.G)
-        if split:
-            torch.cuda.current_stream().wait_stream(self._comm_stream())
+            if split:
+                torch.cuda.current_stream().wait_stream(self._comm_stream())
 
     def _block_out_shape(self, blk):
         sp = self.specs[blk + ".conv1"]

@@ -8,6 +8,7 @@ losses): reconstruction 3e-2, mu / log_var / perturbation 6e-2 in relative L2; l
 |diff| < 0.75 LSB with > 98.5 % of pixels within 4 LSB."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -412,15 +413,25 @@ def _classifier_accuracy_once(arr, targets, test, act_dtype, seed):
     scheduler = cfg.scheduler(optimizer)
     trainer = Trainer(cfg.criterion(), ld, None, cfg, datasets_generator=g2, iters=1)
     ENV = new_env()
-    train(1, model, None, None, optimizer, scheduler, cfg.criterion(), trainer, Evaluator(ld, None, cfg), ENV, ld, cfg)
+
+    class _LateEvaluator(Evaluator):
+        """Only the last three epochs' evaluations are read below: the earlier ones are skipped (their history entries stay 0)."""
+
+        def eval(self, epoch, model):
+            if epoch > CLASSIFIER_EPOCHS - 3:
+                super().eval(epoch, model)
+
+    train(1, model, None, None, optimizer, scheduler, cfg.criterion(), trainer, _LateEvaluator(ld, None, cfg), ENV, ld, cfg)
+    print(".", end="", file=sys.__stderr__, flush=True)      # a sign of life past pytest's capture: this test runs for minutes
     # mean over the last three epochs (small learning rates at the end of the cosine schedule): the +-1 point band is about
     # three standard deviations of one evaluation's sampling noise on 16 384 test images
     return float(np.mean(ENV["eval_history"][-3:]))
 
 
-def _train_dvae(ds, test, dtype, epochs=30):
-    """A D-VAE trained briefly on the poisoned set through the drop-in trainer (fused route), stage-1 constants."""
-    gen = DD.DatasetGenerator(ds, test, train_batch_size=128, eval_batch_size=512, device="cuda", seed=2)
+def _train_dvae(ds, test, dtype, epochs=30, seed=2):
+    """A D-VAE trained briefly on the poisoned set through the drop-in trainer (fused route), stage-1 constants.
+    ``seed``: the loader's shuffling (another order of the batches is another trained network)."""
+    gen = DD.DatasetGenerator(ds, test, train_batch_size=128, eval_batch_size=512, device="cuda", seed=seed)
     loaders = gen.getDataLoader(train_shuffle=True, train_drop_last=True)
     torch.manual_seed(0)
     m = make_model(dtype=dtype)
@@ -474,8 +485,13 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
                    no shortcut and the leg shows nothing
       oracle       purified by the CPU oracle with the fp32-trained D-VAE's parameters and injected noise
       f32, bf16    the same parameters and noise through the fp32 / bf16 HIP purification: each within +-1 point of oracle
-      bf16-trained a D-VAE trained AND run in bf16 (what bench.py times): another trained network, so it is held to the
-                   claim that matters -- it purifies as well: >= oracle - 3 points
+                   (+ two standard errors of the classifier-seed noise, measured on the three runs per arm)
+      f32-trained, bf16-trained
+                   D-VAEs trained AND run in fp32 / in bf16 (what bench.py times).  Every training run is another network,
+                   and a 960-step D-VAE is a noisy purifier: with nothing changed but the order of the batches the clean
+                   accuracy behind it moves between 59 and 71 % in either dtype (a summation-order change in one conv
+                   kernel re-rolls it just the same).  So the claim that matters -- training in bf16 purifies as well as
+                   training in fp32 -- is held on the mean over three trainings each: bf16 >= f32 - 6 points
       sign-error   the fp32 path with the perturbation added instead of subtracted: a purifier with one defect must land
                    outside the +-1 band (below oracle by more than 3 points), else the leg could not see it
     and the purified arms must recover >= 8 points over the poisoned control."""
@@ -499,23 +515,37 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
         purified[dt] = _purify_hip(sd, ds, eps, dt)
     dq = np.abs(purified["f32"].astype(int) - purified["oracle"].astype(int))
     assert dq.max() <= 1 and (dq != 0).mean() <= 0.005
-    m16 = _train_dvae(ds, test, "bf16")
-    sd16 = {k: v.detach().cpu().clone() for k, v in m16.state_dict().items()}
-    purified["bf16-trained"] = _purify_hip(sd16, ds, eps, "bf16")
     purified["sign-error"] = _purify_with_sign_error(sd, ds, eps)
+    runs = {}
     for tag, arr in purified.items():
-        # the three arms of the +-1 band: two classifier seeds each (1-LSB differences between two purified sets send two
-        # trainings apart chaotically; one run's noise is about half a point)
-        accs[tag] = _classifier_accuracy(arr, ds.targets, test, seeds=(1, 2) if tag in ("oracle", "f32", "bf16") else (1,))
+        # the three arms of the +-1 band: three classifier seeds each.  1-LSB differences between two purified sets send
+        # two trainings apart chaotically (the fp32 arm differs from the oracle's set in < 0.5 % of the pixels by one grey
+        # level and its three runs still spread over a point), so the band is +-1 point plus two standard errors of the
+        # difference of the two means, estimated from the runs themselves and printed.
+        seeds = (1, 2, 3) if tag in ("oracle", "f32", "bf16") else (1,)
+        runs[tag] = [_classifier_accuracy_once(arr, ds.targets, test, "f32", sd_) for sd_ in seeds]
+        accs[tag] = float(np.mean(runs[tag]))
+    se = {k: float(np.std(runs[k], ddof=1) / np.sqrt(len(runs[k]))) for k in ("oracle", "f32", "bf16")}
+    band = {k: 1.0 + 2.0 * float(np.hypot(se[k], se["oracle"])) for k in ("f32", "bf16")}
+    print("per-seed accuracies:", {k: [round(a, 2) for a in v] for k, v in runs.items()}, "bands:", {k: round(v, 2) for k, v in band.items()})
+    trained = {"f32": [], "bf16": []}
+    for dt in ("f32", "bf16"):
+        for seed in (2, 3, 4):
+            mt = m if (dt, seed) == ("f32", 2) else _train_dvae(ds, test, dt, seed=seed)
+            sdt = {k: v.detach().cpu().clone() for k, v in mt.state_dict().items()}
+            trained[dt].append(_classifier_accuracy(_purify_hip(sdt, ds, eps, dt), ds.targets, test))
+        accs[dt + "-trained"] = float(np.mean(trained[dt]))
+    print("clean test accuracy (%) behind three D-VAE trainings per dtype:", {k: [round(a, 2) for a in v] for k, v in trained.items()})
     # the classifier stage itself in bf16 on the oracle-purified set
     accs["oracle, bf16 classifier"] = _classifier_accuracy(purified["oracle"], ds.targets, test, act_dtype="bf16")
     print("clean test accuracy (%) of a ResNet-18 trained on each version of the set:",
           {k: round(v, 2) for k, v in accs.items()})
     assert accs["clean"] - accs["poisoned"] >= 20.0, accs
-    assert abs(accs["f32"] - accs["oracle"]) <= 1.0 and abs(accs["bf16"] - accs["oracle"]) <= 1.0, accs
-    assert accs["bf16-trained"] >= accs["oracle"] - 3.0, accs
+    assert abs(accs["f32"] - accs["oracle"]) <= band["f32"] and abs(accs["bf16"] - accs["oracle"]) <= band["bf16"], (accs, band)
+    assert max(band.values()) < 3.0, band                    # (the sign-error arm below must stay outside it)
+    assert accs["bf16-trained"] >= accs["f32-trained"] - 6.0, accs
     assert accs["sign-error"] < accs["oracle"] - 3.0, accs
-    for k in ("oracle", "f32", "bf16", "bf16-trained"):
+    for k in ("oracle", "f32", "bf16", "f32-trained", "bf16-trained"):
         assert accs[k] >= accs["poisoned"] + 8.0, accs
     assert abs(accs["oracle, bf16 classifier"] - accs["oracle"]) <= 3.0, accs
 
