@@ -17,6 +17,7 @@ What it computes, by reference line:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -241,6 +242,7 @@ class DVAEEngine:
         self.inference_noise16 = dtype == BF16
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
         self._overlap = self.dev.type == "cuda"   # weight gradients on a side stream (see _wgrad)
+        self._two_stream_decoders = os.environ.get("DVAE_TWO_STREAM_DECODERS", "1") != "0"
 
     # ------------------------------------------------------------------------------------------
     def _desc(self, sp: ConvSpec, b: int) -> ConvDesc:
@@ -523,8 +525,19 @@ class DVAEEngine:
         _, _, z = self.latent(stem_out, eps, b, keep_eps=train, need_mulv=train if need_mulv is None else need_mulv, y=y)
         if isinstance(eps, PhiloxEps):
             eps = self.buf("eps", (self.B, self.h, self.h, self.Ld), torch.float32) if train else None
-        rec_pre = self._decoder("decoder", z, b, train) if (train or need_rec) else None
-        p = self.perturb(stem_out, z, y, b, train)
+        if (not train) and need_rec and self._two_stream_decoders and self._fuse_in and self._fuse_stats and self.dev.type == "cuda":
+            # The two decoders of an inference forward are independent chains of six launches each (on the fused route
+            # they share no workspace): decoder_p runs on the side stream, so that a launch of one chain fills the CUs
+            # the other chain's launch has already left and the gaps between its dependent launches.
+            side, cur = self._side_stream(), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                p = self.perturb(stem_out, z, y, b, train)
+            rec_pre = self._decoder("decoder", z, b, train)
+            cur.wait_stream(side)
+        else:
+            rec_pre = self._decoder("decoder", z, b, train) if (train or need_rec) else None
+            p = self.perturb(stem_out, z, y, b, train)
         self._last = dict(b=b, x0=x0, y=y, eps=eps, stem_out=stem_out, train=train)
         return rec_pre, p
 
