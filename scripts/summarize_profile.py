@@ -17,7 +17,7 @@ ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"       # usage: python script
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
-K = "void dvae::conv_wreg_bf16_kernel<64, 64, 1, false>(dvae::HaloArgs)"
+K = "void dvae::conv_wreg_bf16_kernel<64, 64, 1, false, false, false>(dvae::HaloArgs)"   # plain: no residual, no input normalisation, no statistics
 
 shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, ROUND + "_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_trace.csv"))))
