@@ -30,7 +30,7 @@ struct RgbArgs {
     const float* shift;      // per output channel, or null (0)
     const float* in_ss;      // optional input normalisation [B][2][32]: x <- relu?(x * scale + shift) while staging
     int in_relu;
-    int B, H, W, N, Ktot;
+    int B, H, W, N, Ktot, tiles_per_wg;
     int tap[3][3];           // packed tap index of offset (dy - 1, dx - 1)
     TileGrid g;              // tiles of an image: W / 32 per tile row, H / 8 tile rows
 };
@@ -153,13 +153,16 @@ __global__ __launch_bounds__(256, 4) void conv_rgb_bf16_kernel(const RgbArgs a) 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) load_tile(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    // a workgroup walks a contiguous run of tiles (whole images in order): the two rows neighbouring tiles share are then
+    // read by the same CU one tile apart and found in L2
+    int tile = blockIdx.x * a.tiles_per_wg;
+    const int tend = tile + a.tiles_per_wg < ntiles ? tile + a.tiles_per_wg : ntiles;
+    if (tile < tend) load_tile(tile);
+    for (; tile < tend; ++tile) {
         store_tile();
         __syncthreads();                                   // the tile's rows (first time: the zeroed patches) are visible
-        const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);                // in flight under the MFMAs and the combine
+        const int next = tile + 1;
+        if (next < tend) load_tile(next);                  // in flight under the MFMAs and the combine
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
 #pragma unroll
@@ -232,7 +235,8 @@ static bool try_launch_rgb_bf16(const GemmPlan& P, const void* in, const void* w
     for (int t = 0; t < 9; ++t) a.tap[ph.dy[t] + 1][ph.dx[t] + 1] = t;
     make_tile_grid(P.Wout / 32, P.Hout / 8, 0, a.g);
     const long ntiles = (long)P.B * a.g.tpi;
-    const int gx = ntiles < 256 * 4 ? (int)ntiles : 256 * 4;
+    a.tiles_per_wg = (int)((ntiles + 256 * 4 - 1) / (256 * 4));       // four workgroups per CU
+    const int gx = (int)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg);
     if (P.Wout == 32) hipLaunchKernelGGL(conv_rgb_bf16_kernel<false>, dim3(gx), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(conv_rgb_bf16_kernel<true>, dim3(gx), dim3(256), 0, st, a);
     return true;
