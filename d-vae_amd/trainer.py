@@ -359,7 +359,7 @@ class _HostDrain:
 
 
 @torch.no_grad()
-def purify_dataset(model_s, dataset, stage: int, batch: int = 1024, seed: int = 0, device="cuda", act_dtype=None,
+def purify_dataset(model_s, dataset, stage: int, batch: int = 2048, seed: int = 0, device="cuda", act_dtype=None,
                    timings: dict | None = None, overlap_tail: bool = True):
     """The epoch-0 branch of ``Trainer.train`` (main_vae_disentangle.py:59-69) for a whole dataset:
     overwrites ``dataset.data`` in place with the purified uint8 images and returns the recorded
@@ -471,7 +471,7 @@ class Trainer:
     train the classifier on the purified set with stock torch ops (not on the accelerated path)."""
 
     def __init__(self, criterion, data_loader, logger, config, global_step=0, target="train_dataset",
-                 datasets_generator=None, exp_name=".", iters=0, purify_batch=1024, seed=0, act_dtype=None):
+                 datasets_generator=None, exp_name=".", iters=0, purify_batch=2048, seed=0, act_dtype=None):
         self.criterion, self.data_loader, self.logger, self.config = criterion, data_loader, logger, config
         lf = getattr(config, "log_frequency", None)
         self.log_frequency = lf if lf is not None else 100

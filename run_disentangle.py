@@ -75,7 +75,7 @@ def parse(argv=None):
     p.add_argument("--spatial_emb", action="store_true")
     # not in the reference
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"], help="arithmetic of the D-VAE path")
-    p.add_argument("--purify_batch", default=1024, type=int)
+    p.add_argument("--purify_batch", default=2048, type=int)
     p.add_argument("--epochs_s", default=None, type=int, help="override config_s.epochs (D-VAE epochs per stage)")
     p.add_argument("--epochs", default=None, type=int, help="override config.epochs (classifier epochs)")
     p.add_argument("--synthetic_n", default=50000, type=int)

@@ -13,7 +13,8 @@ import statistics as st
 
 import sys
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"       # usage: python scripts/summarize_profile.py [r02|r03]
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"       # usage: python scripts/summarize_profile.py [r02|r03] [images per probed launch]
+IMAGES = int(sys.argv[2]) if len(sys.argv) > 2 else 2048  # bench.py's default purification batch at 32x32 (1024 until the middle of round 3)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
@@ -22,11 +23,11 @@ K = "void dvae::conv_wreg_bf16_kernel<64, 64, 1, false, false, false>(dvae::Halo
 shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, ROUND + "_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_trace.csv"))))
 us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"] == K]
-# the 1024-image launches: the train step's 128-image ones are 4x shorter, and a launch that pays a one-off cost (the
+# the purification launches: the train step's 128-image ones are many times shorter, and a launch that pays a one-off cost (the
 # first of the process) several times longer
 p90 = sorted(us)[int(0.9 * len(us))]
 big = [x for x in us if 0.6 * p90 < x < 2.0 * p90]
-probe = {"kernel": K, "launches_1024_images": len(big), "mean_us": st.mean(big), "min_us": min(big), "max_us": max(big),
+probe = {"kernel": K, "images_per_launch": IMAGES, "launches_of_that_size": len(big), "mean_us": st.mean(big), "min_us": min(big), "max_us": max(big),
          "launches_all_shapes": len(us), "outliers_above_us": [x for x in us if x >= 2.0 * p90],
          "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py"}
 json.dump(probe, open(os.path.join(DST, ROUND + "_probe_kernel.json"), "w"), indent=1)
@@ -41,11 +42,11 @@ def counter(name):
 
 f, nf, fmin, fmax = counter("fetch")
 w, nw, wmin, wmax = counter("write")
-traffic = {"kernel": K, "launch": "3x3 conv 64->64 @32x32, 1024 images (purification region of bench.py)",
+traffic = {"kernel": K, "launch": f"3x3 conv 64->64 @32x32, {IMAGES} images (purification region of bench.py)", "images_per_launch": IMAGES,
            "FETCH_SIZE_KB": {"mean": f, "launches": nf, "min": fmin, "max": fmax},
            "WRITE_SIZE_KB": {"mean": w, "launches": nw, "min": wmin, "max": wmax},
            "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes)",
-           "hbm_bytes": (2 * f + w) * 1024, "algorithmic_bytes": 2 * 1024 * 1024 * 64 * 2,
+           "hbm_bytes": (2 * f + w) * 1024, "algorithmic_bytes": 2 * IMAGES * 1024 * 64 * 2,
            "commands": ["rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-train --no-f32 --no-pass --no-cpu-baseline",
                         "rocprofv3 --pmc WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-train --no-f32 --no-pass --no-cpu-baseline"]}
 json.dump(traffic, open(os.path.join(DST, ROUND + "_traffic_bf16.json"), "w"), indent=1)
