@@ -21,7 +21,9 @@ struct PointArgs {
     const float* scale;        // per output channel or NULL (1)
     const float* shift;        // per output channel or NULL (0)
     int relu, ntiles, Ktot;    // tiles of 128 output pixels
-    // optional second output: out2 = out + emb[labels[image]][pixel] (class embedding in activation layout, hw pixels per image)
+    // optional second output: out2 = out + emb[labels[image]][pixel] (class embedding in activation layout, hw pixels per
+    // image; emb_px = 0: one row per class, the same for every pixel)
+    int emb_px;              // table rows per image: hw (spatial table) or 0
     const bf16* emb;
     const int64_t* labels;
     bf16* out2;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
             const long m0 = (long)tile * 128;
             const int b = (int)(m0 / a.hw), px0 = (int)(m0 - (long)b * a.hw) + ph * 64;
             ob2 = a.out2 + (m0 + ph * 64) * PT_N + cq * 32;
-            eb = a.emb + ((long)a.labels[b] * a.hw + px0) * PT_N + cq * 32;
+            eb = a.emb + (a.emb_px ? (long)a.labels[b] * a.hw + px0 : (long)a.labels[b]) * PT_N + cq * 32;
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(512) void conv_point_bf16_kernel(const PointArgs a)
             if (a.out2) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    ev[i] = *reinterpret_cast<const u32x4*>(eb + (long)(p * 32 + i * 16 + sp) * PT_N + sc8 * 8);
+                    ev[i] = *reinterpret_cast<const u32x4*>(eb + (a.emb_px ? (long)(p * 32 + i * 16 + sp) * PT_N : 0l) + sc8 * 8);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -187,12 +189,13 @@ static bool point_applicable(const GemmPlan& P) { return point_cin(P) != 0; }
 static bool try_launch_point_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                   const float* shift, const void* res, int relu, int accumulate, int out_f32,
                                   hipStream_t st, const void* emb = nullptr, const int64_t* labels = nullptr,
-                                  void* out2 = nullptr) {
+                                  void* out2 = nullptr, int emb_plain = 0) {
     const int cin = point_cin(P);
     if (res || accumulate || out_f32 || !cin) return false;
     if (out2 && (cin != 256 || (P.Hout * P.Wout) % 128)) return false;   // the second output wants a tile inside one image
     PointArgs a;
     a.emb = (const bf16*)emb; a.labels = labels; a.out2 = (bf16*)out2; a.hw = P.Hout * P.Wout;
+    a.emb_px = emb_plain ? 0 : a.hw;
     a.in = (const bf16*)in; a.wp = (const bf16*)wp + P.ph[0].koff; a.out = (bf16*)out; a.scale = scale; a.shift = shift;
     a.relu = relu; a.ntiles = (int)((long)P.B * P.Hout * P.Wout / 128); a.Ktot = P.Ktot;
     a.ho = P.Hout; a.wo = P.Wout; a.lho = ilog2_exact(P.Hout); a.lwo = ilog2_exact(P.Wout);

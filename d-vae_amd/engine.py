@@ -233,7 +233,8 @@ class DVAEEngine:
                                for n in ("decoder1.1", "decoder2.0"))
         self._fuse_head = bool(self.lib.dvae_fc_reparam_supported(C.byref(self._desc(self.specs["fc"], 1)), self.Ld, dtype))
         # post_conv can leave decoder_p's input (z + class embedding) behind as a second output
-        self._fuse_emb = bool(cfg.sample_wise and not cfg.use_y and cfg.spatial_emb and
+        # (either table: the spatial one, or the plain class embedding -- one row for every pixel of an image)
+        self._fuse_emb = bool(cfg.sample_wise and not cfg.use_y and
                               self.lib.dvae_conv_supports_emb_out(C.byref(self._desc(self.specs["post_conv"], 1)), dtype))
         # Purification draws its reparameterisation noise in-kernel.  bf16 engines take it from a 16-bit-uniform stream
         # (stream id bit 31: eight normals per Philox call, half the cost per normal; eps feeds a product that is rounded
@@ -360,7 +361,7 @@ class DVAEEngine:
         """emb = (packed table, labels, second output): the conv also writes y + table[label] (decoder_p's input)."""
         et, el, eo = emb if emb is not None else (None, None, None)
         ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu), ptr(out_stats),
-                      ptr(et), ptr(el), ptr(eo))
+                      ptr(et), ptr(el), ptr(eo), int(not self.cfg.spatial_emb))
         pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
         if pr:
             pr[1][0].record()

@@ -72,12 +72,15 @@ typedef struct dvae_epilogue {
      * dvae_conv_out_stats_floats() gives the size, 0 where the conv cannot produce them; NULL = off. */
     float* out_stats;
     /* Optional second output (inference): emb_out = y + emb_table[emb_labels[b]], the input of decoder_p
-     * (emb_p(y).reshape(stem_out.shape) + z, resnet.py:2212, :2219), with emb_table the spatial table in activation
-     * layout as dvae_emb_pack leaves it ([classes][H*W][act channels]) and emb_out shaped like y.  Same values as
+     * (emb_p(y).reshape(stem_out.shape) + z, resnet.py:2212, :2219), with emb_table the table in activation layout as
+     * dvae_emb_pack leaves it (spatial: [classes][H*W][act channels]; plain, see emb_plain: [classes][act channels]) and
+     * emb_out shaped like y.  Same values as
      * dvae_emb_add_fwd on the stored y.  Only where dvae_conv_supports_emb_out() says so; emb_out == NULL = off. */
     const void* emb_table;
     const int64_t* emb_labels;
     void* emb_out;
+    int32_t emb_plain;        /* 1: emb_table is the plain class embedding [classes][act channels] (spatial_emb off,
+                               * resnet.py:2214-2216), one row for every pixel of an image; 0: the spatial table */
 } dvae_epilogue;
 
 const char* dvae_version(void);
