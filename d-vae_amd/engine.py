@@ -361,7 +361,7 @@ class DVAEEngine:
         """emb = (packed table, labels, second output): the conv also writes y + table[label] (decoder_p's input)."""
         et, el, eo = emb if emb is not None else (None, None, None)
         ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu), ptr(out_stats),
-                      ptr(et), ptr(el), ptr(eo), int(not self.cfg.spatial_emb))
+                      ptr(et), ptr(el), ptr(eo), int(emb is not None and not self.cfg.spatial_emb))
         pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
         if pr:
             pr[1][0].record()

@@ -251,11 +251,12 @@ def release_staging():
         _POOL.pop().shutdown(wait=True)
 
 
-def _copy_stream():
-    dev = torch.cuda.current_device()
-    st = _COPY_STREAM.get(dev)
+def _copy_stream(kind="down"):
+    """Side streams kept per device: "down" for the drains' device-to-host copies, "up" for uploads."""
+    key = (torch.cuda.current_device(), kind)
+    st = _COPY_STREAM.get(key)
     if st is None:
-        st = _COPY_STREAM[dev] = torch.cuda.Stream()
+        st = _COPY_STREAM[key] = torch.cuda.Stream()
     return st
 
 
@@ -379,7 +380,9 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 2048, seed: int = 
     dev = torch.device(device)
     if act_dtype is not None:
         model_s.act_dtype = act_dtype
-    data = torch.from_numpy(dataset.data[lo:hi]).to(dev)
+    # The shard's uint8 images go to the device batch by batch on the copy stream, a batch ahead of the kernels that read
+    # them (a pageable copy of the whole shard up front is 7 ms of a 0.13 s pass in which the GPU does nothing)
+    host_u8 = torch.from_numpy(dataset.data[lo:hi])
     labels = torch.from_numpy(np.asarray(dataset.targets[lo:hi], dtype=np.int64)).to(dev)
     S = dataset.data.shape[1]
     was_training = model_s.training
@@ -390,6 +393,27 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 2048, seed: int = 
         D.broadcast_(eng.R, 0)
         eng.fold_valid = False
     eng.seed = seed
+    cuda = dev.type == "cuda"
+    data = torch.empty(host_u8.shape, dtype=torch.uint8, device=dev)
+    up_stream = _copy_stream() if cuda else None
+    up_events = {}
+
+    def upload(first):
+        """rows [first, first + eng.B) of the shard -> device (asynchronous to the kernels in flight)"""
+        if first >= hi - lo or first in up_events:
+            return
+        last = min(hi - lo, first + eng.B)
+        if cuda:
+            with torch.cuda.stream(up_stream):
+                data[first:last].copy_(host_u8[first:last])
+                ev = torch.cuda.Event()
+                ev.record()
+            up_events[first] = ev
+        else:
+            data[first:last].copy_(host_u8[first:last])
+            up_events[first] = None
+
+    upload(0)
     out = torch.empty_like(data)
     noise = torch.empty(hi - lo, 3, S, S, device=dev)
     if timings is not None:
@@ -401,7 +425,6 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 2048, seed: int = 
     # rank's perturbations and no collective carries them; after a barrier every rank copies the other shards' uint8 rows
     # into its own dataset.data and rank 0 owns the float64 buffer.  Ranks spread over nodes: gather, then one chunked copy.
     drain = shared = None
-    cuda = dev.type == "cuda"
     if world == 1 and cuda and overlap_tail:
         res = torch.empty(n, 3, S, S, dtype=torch.float64)
         drain = _HostDrain(torch.from_numpy(dataset.data), res, eng.B, tuple(data.shape[1:]), (3, S, S))
@@ -413,7 +436,10 @@ def purify_dataset(model_s, dataset, stage: int, batch: int = 2048, seed: int = 
                                also_u8=torch.from_numpy(dataset.data)[lo:hi])
     for first in range(0, hi - lo, eng.B):
         b = min(eng.B, hi - lo - first)
+        if up_events.get(first) is not None:
+            torch.cuda.current_stream().wait_event(up_events[first])
         eng.purify_batch(data, out, noise, labels, first, b, stage, global_first=lo + first)
+        upload(first + eng.B)
         if drain is not None:
             drain.push(first, first + b, out[first:first + b], noise[first:first + b])
     if timings is not None:
