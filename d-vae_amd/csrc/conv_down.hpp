@@ -24,6 +24,8 @@
 // second wave per SIMD overlaps nothing by itself.  Workgroups are persistent over a contiguous run of tiles (whole
 // images in order, so the input rows two tiles share are found in L2).
 #pragma once
+#include <type_traits>
+
 #include "conv_halo.hpp"
 
 namespace dvae {
@@ -181,8 +183,9 @@ __global__ __launch_bounds__(256, 2) void conv_down_bf16_kernel(const DownArgs a
 
     // One tile: 36 MFMAs into accN; between them the epilogue of accO (tile - 1, if any) and, for each halo vector, its
     // store (tile + 1) and reload (tile + 2).
-    auto phase = [&](f32x16& accN, const f32x16& accO, int tile, int it) {
-        const int cur = it & 1;
+    // (cur = parity of the tile's position in the run, a compile-time constant of each of the loop body's two calls)
+    auto phase = [&](auto CUR, f32x16& accN, const f32x16& accO, int tile, bool first) {
+        constexpr int cur = decltype(CUR)::value;
         const unsigned char* hb = smem + cur * DOWN_HALO_BYTES;
         // Nothing below is conditional (a memory operation inside a branch is waited for where the branch ends).  The
         // first tile has no predecessor: its "previous" epilogue works on an undefined accumulator and is drained to the
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_bf16_kernel(const DownArgs a
             __builtin_amdgcn_sched_barrier(0);                 // keep reads and side work where they were placed
         }
         __syncthreads();                                       // patch and next halo complete; everyone is done with this halo
-        drain(it > 0 ? tile - 1 : tile, cur ^ 1);
+        drain(first ? tile : tile - 1, cur ^ 1);
     };
 
     // first tile's halo, and the registers of the second
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void conv_down_bf16_kernel(const DownArgs a
     bool last_a = true;
 #pragma nounroll
     while (tile < t1) {
-        phase(accA, accB, tile, it);
+        phase(std::integral_constant<int, 0>{}, accA, accB, tile, it == 0);
         ++tile; ++it; last_a = true;
         if (tile >= t1) break;
-        phase(accB, accA, tile, it);
+        phase(std::integral_constant<int, 1>{}, accB, accA, tile, false);
         ++tile; ++it; last_a = false;
     }
     // the last tile's epilogue and drain (patch of iteration it - 1)

@@ -12,6 +12,7 @@
 #include "conv_point.hpp"
 #include "conv_rgb.hpp"
 #include "conv_down.hpp"
+#include "conv_up.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -50,6 +51,7 @@ static float* static_scratch_for_current_device() {
 static std::atomic<int> g_opt_wreg{1};
 static std::atomic<int> g_opt_rgb{1};
 static std::atomic<int> g_opt_down{1};
+static std::atomic<int> g_opt_up{1};
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
@@ -78,6 +80,7 @@ int dvae_set_option(const char* name, int value) {
     if (!strcmp(name, "conv_wreg")) { g_opt_wreg.store(value != 0); return DVAE_OK; }
     if (!strcmp(name, "conv_rgb")) { g_opt_rgb.store(value != 0); return DVAE_OK; }
     if (!strcmp(name, "conv_down")) { g_opt_down.store(value != 0); return DVAE_OK; }
+    if (!strcmp(name, "conv_up")) { g_opt_up.store(value != 0); return DVAE_OK; }
     DVAE_FAIL(DVAE_EINVAL, "set_option: unknown option '%s'", name);
 }
 const char* dvae_last_error(void) { return g_err; }
@@ -196,6 +199,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused input normalisation / output statistics unavailable for this launch");
     if (g_opt_down.load() && try_launch_down_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
         DVAE_CHECK_LAUNCH("conv_down");
+        return DVAE_OK;
+    }
+    if (g_opt_up.load() && try_launch_up_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_up");
         return DVAE_OK;
     }
     if (try_launch_image_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
