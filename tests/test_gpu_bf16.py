@@ -294,6 +294,8 @@ PERSISTENT = [
     (64, 128, 3, 2, 1, False, 32, "bnrelu", 50),  # ... one tile per workgroup, scale / shift / ReLU
     (64, 128, 3, 2, 1, False, 96, "bnrelu", 130), # ... 36 tiles per image
     (32, 3, 3, 1, 1, True, 32, "f32", 50),        # decoder head kernel: fewer tiles than workgroups
+    (128, 64, 4, 2, 1, True, 16, "bnrelu", 37),   # transposed-conv weights-in-registers kernel: 2 tiles per workgroup, scale / shift / ReLU
+    (128, 64, 4, 2, 1, True, 16, "plain", 161),   # ... 6 tiles per workgroup, 4 in the last
 ]
 
 
@@ -326,6 +328,39 @@ def test_down_conv_epilogue(hin, B):
     finally:
         L.check(lib.dvae_set_option(b"conv_down", 1))
     assert rel_err(ya.float().cpu(), yb.float().cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("B", [1, 5, 64])
+def test_up_conv_epilogue(B):
+    """ConvTranspose2d k4 s2 p1 128 -> 64 on 16x16 maps (resnet.py:2139-2167: the decoders' first layer) with a per-channel
+    scale / shift + ReLU epilogue, against torch on the bf16-rounded operands: <= 6e-3 of scale (one bf16 rounding); and
+    against the image-resident kernel on the same launch (the dedicated kernel switched off): the same fp32 sums in the
+    same order, so the same bits."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    q = lambda t: t.bfloat16().float()      # noqa: E731
+    w = q(torch.randn(128, 64, 4, 4, generator=g) / 32.0)
+    x = q(torch.randn(B, 128, 16, 16, generator=g))
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    want = torch.relu(F.conv_transpose2d(x, w, None, stride=2, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    d = L.ConvDesc(B, 16, 16, 128, 64, 4, 4, 2, 1, 1)
+    st = L.stream()
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    ya = torch.full((B, 32, 32, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    scd, shd = sc.cuda(), sh.cuda()
+    ep = L.Epilogue(scd.data_ptr(), shd.data_ptr(), None, 1, 0)
+    xa = to_act(x, L.BF16)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), ya.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(ya, 64), want) < 6e-3
+    yb = torch.full_like(ya, 7.0)
+    L.check(lib.dvae_set_option(b"conv_up", 0))
+    try:
+        L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), yb.data_ptr(), C.byref(d), L.BF16, st))
+    finally:
+        L.check(lib.dvae_set_option(b"conv_up", 1))
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
 
 
 @pytest.mark.parametrize("cfg", PERSISTENT, ids=lambda c: "-".join(str(v) for v in c))
