@@ -1,5 +1,5 @@
-// ConvTranspose2d k4 s2 p1, 128 -> 64 channels, on 16x16 maps (the decoders' first layer at 32x32 images), weights in
-// registers.
+// ConvTranspose2d k4 s2 p1, 128 -> 64 channels (the decoders' first layer), on maps whose width is a multiple of 16 and
+// whose height is even (16x16 at 32x32 images, 32x32 at 64x64, 112x112 at 224x224), weights in registers.
 //
 // The transposed conv is four output-parity phases; phase (py, px) is a 2x2-tap conv of the input map into the output
 // pixels (2 y + py, 2 x + px): K = 4 taps x 128 channels = 512, N = 64.  A workgroup is four waves, ONE PER PHASE, one
@@ -12,10 +12,10 @@
 //
 // Between the MFMAs of a tile (fully unrolled, scheduling barriers keep the placement) a wave runs the PREVIOUS tile's
 // epilogue (two accumulator sets alternate) into an LDS patch that interleaves the four phases into whole output rows
-// -- a tile's output is four full rows of the 32-pixel-wide image: 16 KB contiguous -- and the staging of the tiles ahead:
-// each of a thread's five halo vectors is stored for tile + 1 and at once re-loaded for tile + 2.  No memory operation of
-// the tile loop is conditional.  One barrier per tile, then the drain of the previous patch.  Persistent over a contiguous
-// run of tiles (whole images in order).
+// -- a tile's output is four output rows x 32 pixels: four 4 KB runs, 16 KB contiguous on a 16-wide map -- and the staging
+// of the tiles ahead: each of a thread's five halo vectors is stored for tile + 1 and at once re-loaded for tile + 2
+// (through a buffer descriptor: lanes outside the map read zeros).  No memory operation of the tile loop is conditional.  One barrier per tile, then the drain of the previous patch.
+// Persistent over a contiguous run of tiles (an image's tiles row by row, images in order).
 #pragma once
 #include <type_traits>
 
@@ -24,13 +24,24 @@
 namespace dvae {
 
 struct UpArgs {
-    const void* in;          // bf16 [B][16][16][128]
+    const void* in;          // bf16 [B][H][W][128]
     const void* wp;          // packed forward weights [64][Ktot], K = (phase, tap, channel)
-    void* out;               // bf16 [B][32][32][64]
+    void* out;               // bf16 [B][2 H][2 W][64]
     const float* scale;      // per output channel, or null (1)
     const float* shift;      // per output channel, or null (0)
-    int B, Ktot, relu;
+    int B, H, W, Ktot, relu;
     int tiles_per_wg;
+    // tiles of 2 x 16 input positions: ntx = W / 16 across, tpi = ntx * H / 2 per image.  n / d = umulhi(n, ceil(2^32 / d))
+    // + n * (d == 1), exact while n * d < 2^32: branch-free (a branch inside the tile loop ends the basic block the side
+    // work is scheduled in, and every wait behind it is for everything)
+    int ntx, tpi, one_ntx, one_tpi;
+    unsigned inv_ntx, inv_tpi;
+    __device__ __forceinline__ void split(int tile, int& b, int& ty, int& tx) const {
+        b = (int)__umulhi((unsigned)tile, inv_tpi) + tile * one_tpi;
+        const int rem = tile - b * tpi;
+        ty = (int)__umulhi((unsigned)rem, inv_ntx) + rem * one_ntx;
+        tx = rem - ty * ntx;
+    }
     int koff[4];             // first K column of each phase
     signed char dy[4][4], dx[4][4];   // [phase][tap]: input offset of the tap
 };
@@ -55,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
     const int py = wave >> 1, px = wave & 1;
     const bf16* in = reinterpret_cast<const bf16*>(a.in);
     const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
-    const int ntiles = a.B * 8;
+    const int ntiles = a.B * a.tpi;
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
     if (t0 >= t1) return;
@@ -97,33 +108,49 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
         ssl[64 + tid] = a.shift ? a.shift[tid] : 0.f;
     }
 
-    // ---- staging: vector v = tid + 256 k of the 4 x 18 halo pixels (16 chunks each): pixel (tid >> 4) + 16 k, chunk tid & 15
+    // ---- staging: vector v = tid + 256 k of the 4 x 18 halo pixels (16 chunks each): pixel (tid >> 4) + 16 k, chunk tid & 15.
+    // A vector's address is descriptor base + hoff[k] (per lane, fixed for the thread's life) + the tile's origin (uniform).
+    // The descriptor's base lies one map row and one pixel in front of the tensor, so that hoff[k] >= 0; its range check
+    // looks at the per-lane part only, so a lane that must not read (halo pixel outside the map, vector beyond the halo)
+    // sets bit 31 of it and gets zeros: the zero padding costs two instructions per vector and nothing at the LDS store.
     constexpr int HV = 5;
     const int chunk = tid & 15;
-    int hrc[HV];                                           // halo row << 8 | halo column; -1: no such vector
+    const unsigned hbias = (unsigned)((a.W + 1) * 256);
+    unsigned hoff[HV], hst[HV];
+    unsigned m_left = 0, m_right = 0, m_top = 0, m_bot = 0;  // bit k: vector k lies in that border of the halo
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
         const int p = (tid >> 4) + 16 * k;
-        hrc[k] = p < 72 ? ((p / 18) << 8 | (p % 18)) : -1;
+        const int hr = p / 18, hc = p - hr * 18;
+        if (p < 72) {
+            hoff[k] = (unsigned)((hr * a.W + hc) * 256 + chunk * 16);
+            hst[k] = (unsigned)(hr * UP_ROW + hc * UP_PIX + chunk * 16);
+            if (hc == 0) m_left |= 1u << k;
+            if (hc == 17) m_right |= 1u << k;
+            if (hr == 0) m_top |= 1u << k;
+            if (hr == 3) m_bot |= 1u << k;
+        } else {
+            hoff[k] = 0x80000000u;
+            hst[k] = 18 * UP_PIX;                          // a row's padding: written, never read
+        }
     }
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(in)) - hbias, 0, 0x80000000u, 0x00020000);
     u32x4 hreg[HV];
-    unsigned hpad = 0;                                     // bit k: hreg[k] lies outside the map
-    // Vector k of `tile` -> hreg[k].  Unconditional and clamped: a load inside a branch is waited for where the branch ends.
-    auto load_vec = [&](int tile, int k) {
-        const int b = tile >> 3, y0 = (tile & 7) * 2;
-        const unsigned char* img = reinterpret_cast<const unsigned char*>(in) + (long)b * (16 * 16 * 256);   // uniform
-        const int hr = (hrc[k] < 0 ? 0 : hrc[k]) >> 8, hc = (hrc[k] < 0 ? 0 : hrc[k]) & 255;
-        const int iy = y0 - 1 + hr, ix = hc - 1;
-        const bool pad = (unsigned)iy >= 16u || (unsigned)ix >= 16u;
-        hpad = pad ? hpad | (1u << k) : hpad & ~(1u << k);
-        const int cy = iy < 0 ? 0 : (iy > 15 ? 15 : iy), cx = ix < 0 ? 0 : (ix > 15 ? 15 : ix);
-        hreg[k] = *reinterpret_cast<const u32x4*>(img + (unsigned)((cy * 16 + cx) * 256 + chunk * 16));
+    // origin (byte offset of input pixel (2 ty, 16 tx) of its image) and border mask of a tile; both uniform, branch-free
+    auto tile_org = [&](int tile, unsigned& org, unsigned& bad) {
+        int b, ty, tx;
+        a.split(tile, b, ty, tx);
+        org = (unsigned)(((b * a.H + 2 * ty) * a.W + 16 * tx) * 256);
+        bad = (m_left & (0u - (unsigned)(tx == 0))) | (m_right & (0u - (unsigned)(tx == a.ntx - 1))) |
+              (m_top & (0u - (unsigned)(ty == 0))) | (m_bot & (0u - (unsigned)(2 * ty + 2 == a.H)));
+    };
+    auto load_vec = [&](unsigned org, unsigned bad, int k) {
+        const unsigned off = (__builtin_amdgcn_ubfe(bad, k, 1) << 31) | hoff[k];
+        hreg[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, org, 0));
     };
     auto store_vec = [&](int buf, int k) {
-        if (hrc[k] < 0) return;                            // (an LDS store in a branch costs nothing)
-        u32x4 v = hreg[k];
-        if (hpad >> k & 1u) v = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(smem + buf * UP_HALO_BYTES + (hrc[k] >> 8) * UP_ROW + (hrc[k] & 255) * UP_PIX + chunk * 16) = v;
+        *reinterpret_cast<u32x4*>(smem + buf * UP_HALO_BYTES + hst[k]) = hreg[k];
     };
 
     // ---- pixel fragment of tap t, slab s: chunk 2 s + h of input pixel (orow + dy, ox + dx); halo pixel (0, 0) is (-1, -1)
@@ -162,16 +189,18 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
         }
         *reinterpret_cast<u32x2*>(patch + pbuf * UP_PATCH_BYTES + poff + (32 * j + 8 * g) * 2) = u32x2{o[0], o[1]};
     };
-    auto drain = [&](int tile, int pbuf) {                 // the patch as whole pixels: four contiguous output rows
-        const int b = tile >> 3, y0 = (tile & 7) * 2;
-        unsigned char* ob = reinterpret_cast<unsigned char*>(a.out) + ((long)b * 32 + 2 * y0) * (32 * 128);
+    const unsigned orow_bytes = (unsigned)(2 * a.W) * 128u;      // one output row
+    auto drain = [&](int tile, int pbuf) {                 // the patch as whole pixels: 32-pixel runs of four output rows
+        int b, ty, tx;
+        a.split(tile, b, ty, tx);
+        unsigned char* ob = reinterpret_cast<unsigned char*>(a.out) + ((long)b * 2 * a.H + 4 * ty) * orow_bytes + tx * (32 * 128);
         const unsigned char* ps = patch + pbuf * UP_PATCH_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + 256 * i, pix = v >> 3, c = v & 7, col = pix & 31;
-            const unsigned char* s = ps + (pix >> 5) * UP_OROW + col * UP_OPIX + (col >> 4) * 8 + c * 16;
+        for (int i = 0; i < 4; ++i) {                      // (row i of the patch: 256 vectors = 32 pixels x 8 chunks)
+            const int pix = tid >> 3, c = tid & 7;
+            const unsigned char* s = ps + i * UP_OROW + pix * UP_OPIX + (pix >> 4) * 8 + c * 16;
             const u32x2 lo = *reinterpret_cast<const u32x2*>(s), hi = *reinterpret_cast<const u32x2*>(s + 8);
-            *reinterpret_cast<u32x4*>(ob + v * 16) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            *reinterpret_cast<u32x4*>(ob + i * orow_bytes + tid * 16) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
 
@@ -185,6 +214,8 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
         constexpr int cur = decltype(CUR)::value;
         const unsigned char* hb = smem + cur * UP_HALO_BYTES;
         const int tile2 = tile + 2 < t1 ? tile + 2 : t1 - 1;
+        unsigned org2, bad2;
+        tile_org(tile2, org2, bad2);
         constexpr int PF = 2;                              // fragments are read PF steps ahead of their MFMAs
         u32x4 pv[PF + 1];
 #pragma unroll
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
             if (st % 4 == 3) epi_store(accO, cur ^ 1, st / 4);
             if (st % 6 == 2 && st / 6 < HV) {
                 store_vec(cur ^ 1, st / 6);
-                load_vec(tile2, st / 6);
+                load_vec(org2, bad2, st / 6);
             }
             __builtin_amdgcn_sched_barrier(0);             // keep reads and side work where they were placed
         }
@@ -213,12 +244,17 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
     };
 
     // first tile's halo, and the registers of the second
+    {
+        unsigned org, bad;
+        tile_org(t0, org, bad);
 #pragma unroll
-    for (int k = 0; k < HV; ++k) load_vec(t0, k);
+        for (int k = 0; k < HV; ++k) load_vec(org, bad, k);
+        tile_org(t0 + 1 < t1 ? t0 + 1 : t0, org, bad);
 #pragma unroll
-    for (int k = 0; k < HV; ++k) {
-        store_vec(0, k);
-        load_vec(t0 + 1 < t1 ? t0 + 1 : t0, k);
+        for (int k = 0; k < HV; ++k) {
+            store_vec(0, k);
+            load_vec(org, bad, k);
+        }
     }
     __syncthreads();
     f32x16 accA[2], accB[2];
@@ -249,16 +285,18 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
 // true if the plan is a launch of the kernel above
 static bool up_applicable(const GemmPlan& P) {
     if (P.nphase != 4 || P.CgS != 128 || P.Cg != 128 || P.N != 64 || P.NS != 64) return false;
-    if (P.Hin != 16 || P.Win != 16 || P.Hout != 32 || P.Wout != 32 || P.Ktot != 2048) return false;
+    if (P.Hin < 2 || P.Hin % 2 || P.Win < 16 || P.Win % 16 || P.Hout != 2 * P.Hin || P.Wout != 2 * P.Win || P.Ktot != 2048) return false;
+    if (((long)P.B * P.Hin + 2) * P.Win * 256 >= 0x7fffffffL) return false;   // byte offsets into the input are 32-bit
     for (int i = 0; i < 4; ++i) {
         const Phase& ph = P.ph[i];
         if (ph.ntaps != 4 || ph.SY != 1 || ph.SX != 1 || ph.DSY != 2 || ph.DSX != 2 || ph.D0Y != (i >> 1) || ph.D0X != (i & 1) ||
-            ph.Hg != 16 || ph.Wg != 16 || ph.koff != 512 * i)
+            ph.Hg != P.Hin || ph.Wg != P.Win || ph.koff != 512 * i)
             return false;
         for (int t = 0; t < 4; ++t)
             if (ph.dy[t] < -1 || ph.dy[t] > 1 || ph.dx[t] < -1 || ph.dx[t] > 1) return false;
     }
-    return (long)P.B * 8 < 0x7fffffffL;
+    TileGrid tg;
+    return make_tile_grid(P.Win / 16, P.Hin / 2, ((long)P.B + 1) * (P.Win / 16) * (P.Hin / 2), tg);
 }
 
 static bool try_launch_up_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
@@ -266,12 +304,16 @@ static bool try_launch_up_bf16(const GemmPlan& P, const void* in, const void* wp
     if (res || accumulate || out_f32 || !up_applicable(P)) return false;
     UpArgs a;
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift;
-    a.B = P.B; a.Ktot = P.Ktot; a.relu = relu;
+    a.B = P.B; a.H = P.Hin; a.W = P.Win; a.Ktot = P.Ktot; a.relu = relu;
+    a.ntx = P.Win / 16; a.tpi = a.ntx * (P.Hin / 2);
+    a.one_ntx = a.ntx == 1; a.one_tpi = a.tpi == 1;
+    a.inv_ntx = a.ntx > 1 ? (unsigned)(((1ull << 32) + a.ntx - 1) / a.ntx) : 0u;
+    a.inv_tpi = a.tpi > 1 ? (unsigned)(((1ull << 32) + a.tpi - 1) / a.tpi) : 0u;
     for (int i = 0; i < 4; ++i) {
         a.koff[i] = P.ph[i].koff;
         for (int t = 0; t < 4; ++t) { a.dy[i][t] = P.ph[i].dy[t]; a.dx[i][t] = P.ph[i].dx[t]; }
     }
-    const int ntiles = P.B * 8;
+    const int ntiles = P.B * a.tpi;
     a.tiles_per_wg = (ntiles + 255) / 256;                 // one workgroup per CU (a wave per SIMD with all its registers)
     const int gx = (ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     static LdsOptIn lds_opt;

@@ -12,13 +12,14 @@ from dvae_amd import _lib as L  # noqa: E402
 
 lib = L.lib()
 st = L.stream()
-for B in (128, 1024):
-    d = L.ConvDesc(B, 16, 16, 128, 64, 4, 4, 2, 1, 1)
+HIN = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+for B in ((128, 1024) if HIN == 16 else (max(1, 32768 // (HIN * HIN)), max(1, 262144 // (HIN * HIN)))):
+    d = L.ConvDesc(B, HIN, HIN, 128, 64, 4, 4, 2, 1, 1)
     w = torch.randn(128, 64, 4, 4, device="cuda") * 0.05
     pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
     L.check(lib.dvae_conv_pack(w.data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
-    x = torch.relu(torch.randn(B, 16, 16, 128, device="cuda")).bfloat16()
-    y = [torch.empty(B, 32, 32, 64, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
+    x = torch.relu(torch.randn(B, HIN, HIN, 128, device="cuda")).bfloat16()
+    y = [torch.empty(B, 2 * HIN, 2 * HIN, 64, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
     sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda")
     for rep in range(2):
         for opt in (0, 1):
@@ -36,5 +37,5 @@ for B in (128, 1024):
             e1.record()
             torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / n * 1000
-            print(f"B={B} conv_up={opt}: {t:6.1f} us  {67108864 * B / t / 1e6:7.1f} TFLOP/s", flush=True)
+            print(f"B={B} conv_up={opt}: {t:6.1f} us  {67108864 * B * (HIN * HIN // 256) / t / 1e6:7.1f} TFLOP/s", flush=True)
     print("max |new - old| =", float((y[0].float() - y[1].float()).abs().max()), " scale", float(y[0].float().abs().max()), flush=True)

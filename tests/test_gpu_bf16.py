@@ -296,6 +296,7 @@ PERSISTENT = [
     (32, 3, 3, 1, 1, True, 32, "f32", 50),        # decoder head kernel: fewer tiles than workgroups
     (128, 64, 4, 2, 1, True, 16, "bnrelu", 37),   # transposed-conv weights-in-registers kernel: 2 tiles per workgroup, scale / shift / ReLU
     (128, 64, 4, 2, 1, True, 16, "plain", 161),   # ... 6 tiles per workgroup, 4 in the last
+    (128, 64, 4, 2, 1, True, 48, "bnrelu", 60),   # ... 72 tiles per image: three across
 ]
 
 
@@ -330,9 +331,10 @@ def test_down_conv_epilogue(hin, B):
     assert rel_err(ya.float().cpu(), yb.float().cpu()) < 4e-3
 
 
-@pytest.mark.parametrize("B", [1, 5, 64])
-def test_up_conv_epilogue(B):
-    """ConvTranspose2d k4 s2 p1 128 -> 64 on 16x16 maps (resnet.py:2139-2167: the decoders' first layer) with a per-channel
+@pytest.mark.parametrize("hin,B", [(16, 1), (16, 5), (16, 64), (32, 3), (48, 2), (112, 1)])
+def test_up_conv_epilogue(hin, B):
+    """ConvTranspose2d k4 s2 p1 128 -> 64 on 16x16 maps (resnet.py:2139-2167: the decoders' first layer; 32x32 / 112x112 maps
+    at 64x64 / 224x224 images, 48x48 for a tile count that is no power of two) with a per-channel
     scale / shift + ReLU epilogue, against torch on the bf16-rounded operands: <= 6e-3 of scale (one bf16 rounding); and
     against the image-resident kernel on the same launch (the dedicated kernel switched off): the same fp32 sums in the
     same order, so the same bits."""
@@ -340,14 +342,14 @@ def test_up_conv_epilogue(B):
     g = torch.Generator().manual_seed(9)
     q = lambda t: t.bfloat16().float()      # noqa: E731
     w = q(torch.randn(128, 64, 4, 4, generator=g) / 32.0)
-    x = q(torch.randn(B, 128, 16, 16, generator=g))
+    x = q(torch.randn(B, 128, hin, hin, generator=g))
     sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
     want = torch.relu(F.conv_transpose2d(x, w, None, stride=2, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    d = L.ConvDesc(B, 16, 16, 128, 64, 4, 4, 2, 1, 1)
+    d = L.ConvDesc(B, hin, hin, 128, 64, 4, 4, 2, 1, 1)
     st = L.stream()
     pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
     L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
-    ya = torch.full((B, 32, 32, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    ya = torch.full((B, 2 * hin, 2 * hin, 64), 7.0, device="cuda", dtype=torch.bfloat16)
     scd, shd = sc.cuda(), sh.cuda()
     ep = L.Epilogue(scd.data_ptr(), shd.data_ptr(), None, 1, 0)
     xa = to_act(x, L.BF16)
