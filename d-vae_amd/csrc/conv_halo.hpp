@@ -27,14 +27,16 @@
 namespace dvae {
 
 // Tile grid of one image: ntx tiles per tile row, tpi tiles per image; tile index = (image * nty + ty) * ntx + tx.
-// Dividing by the two counts is a shift where the count is a power of two (32x32 and 64x64 images) and otherwise a
-// multiply-high by ceil(2^32 / d), which is exact for dividends below 2^32 / d (make_tile_grid checks the largest one).
+// Dividing by the two counts is a multiply-high by ceil(2^32 / d): exact for every dividend where d is a power of two
+// (32x32 and 64x64 images), otherwise for dividends below 2^32 / d (make_tile_grid checks the largest one).
 struct TileGrid {
     int ntx, tpi;
-    int lx, ltpi;            // log2 of ntx / tpi, or -1
+    int one_ntx, one_tpi;    // 1 if the divisor is 1 (its multiplier would be 2^32), else 0
     unsigned inv_ntx, inv_tpi;
-    __device__ __forceinline__ int div_ntx(int n) const { return lx >= 0 ? n >> lx : (int)__umulhi((unsigned)n, inv_ntx); }
-    __device__ __forceinline__ int div_tpi(int n) const { return ltpi >= 0 ? n >> ltpi : (int)__umulhi((unsigned)n, inv_tpi); }
+    // Branch-free on purpose: a select between a shift and a multiply-high compiles to branches, and a branch inside a
+    // kernel's unrolled tile loop ends the basic block its side work is scheduled in.
+    __device__ __forceinline__ int div_ntx(int n) const { return (int)__umulhi((unsigned)n, inv_ntx) + n * one_ntx; }
+    __device__ __forceinline__ int div_tpi(int n) const { return (int)__umulhi((unsigned)n, inv_tpi) + n * one_tpi; }
     // tile -> image and tile coordinates inside it
     __device__ __forceinline__ void split(int tile, int& b, int& ty, int& tx) const {
         b = div_tpi(tile);
@@ -46,7 +48,7 @@ struct TileGrid {
 // false if the grid's divisions would not be exact for `max_dividend`
 static bool make_tile_grid(int ntx, int nty, long max_dividend, TileGrid& g) {
     g.ntx = ntx; g.tpi = ntx * nty;
-    g.lx = ilog2_exact(ntx); g.ltpi = ilog2_exact(g.tpi);
+    g.one_ntx = ntx == 1; g.one_tpi = g.tpi == 1;
     g.inv_ntx = ntx > 1 ? (unsigned)(((1ull << 32) + ntx - 1) / ntx) : 0u;
     g.inv_tpi = g.tpi > 1 ? (unsigned)(((1ull << 32) + g.tpi - 1) / g.tpi) : 0u;
     return max_dividend >= 0 && max_dividend * g.tpi < (1ll << 32) && max_dividend < 0x7fffffffL;

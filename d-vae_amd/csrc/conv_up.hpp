@@ -31,17 +31,7 @@ struct UpArgs {
     const float* shift;      // per output channel, or null (0)
     int B, H, W, Ktot, relu;
     int tiles_per_wg;
-    // tiles of 2 x 16 input positions: ntx = W / 16 across, tpi = ntx * H / 2 per image.  n / d = umulhi(n, ceil(2^32 / d))
-    // + n * (d == 1), exact while n * d < 2^32: branch-free (a branch inside the tile loop ends the basic block the side
-    // work is scheduled in, and every wait behind it is for everything)
-    int ntx, tpi, one_ntx, one_tpi;
-    unsigned inv_ntx, inv_tpi;
-    __device__ __forceinline__ void split(int tile, int& b, int& ty, int& tx) const {
-        b = (int)__umulhi((unsigned)tile, inv_tpi) + tile * one_tpi;
-        const int rem = tile - b * tpi;
-        ty = (int)__umulhi((unsigned)rem, inv_ntx) + rem * one_ntx;
-        tx = rem - ty * ntx;
-    }
+    TileGrid g;              // tiles of 2 x 16 input positions: W / 16 across, H / 2 down (its divisions are branch-free)
     int koff[4];             // first K column of each phase
     signed char dy[4][4], dx[4][4];   // [phase][tap]: input offset of the tap
 };
@@ -66,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
     const int py = wave >> 1, px = wave & 1;
     const bf16* in = reinterpret_cast<const bf16*>(a.in);
     const bf16* wp = reinterpret_cast<const bf16*>(a.wp);
-    const int ntiles = a.B * a.tpi;
+    const int ntiles = a.B * a.g.tpi;
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
     if (t0 >= t1) return;
@@ -140,9 +130,9 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
     // origin (byte offset of input pixel (2 ty, 16 tx) of its image) and border mask of a tile; both uniform, branch-free
     auto tile_org = [&](int tile, unsigned& org, unsigned& bad) {
         int b, ty, tx;
-        a.split(tile, b, ty, tx);
+        a.g.split(tile, b, ty, tx);
         org = (unsigned)(((b * a.H + 2 * ty) * a.W + 16 * tx) * 256);
-        bad = (m_left & (0u - (unsigned)(tx == 0))) | (m_right & (0u - (unsigned)(tx == a.ntx - 1))) |
+        bad = (m_left & (0u - (unsigned)(tx == 0))) | (m_right & (0u - (unsigned)(tx == a.g.ntx - 1))) |
               (m_top & (0u - (unsigned)(ty == 0))) | (m_bot & (0u - (unsigned)(2 * ty + 2 == a.H)));
     };
     auto load_vec = [&](unsigned org, unsigned bad, int k) {
@@ -192,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_up_bf16_kernel(const UpArgs a) {
     const unsigned orow_bytes = (unsigned)(2 * a.W) * 128u;      // one output row
     auto drain = [&](int tile, int pbuf) {                 // the patch as whole pixels: 32-pixel runs of four output rows
         int b, ty, tx;
-        a.split(tile, b, ty, tx);
+        a.g.split(tile, b, ty, tx);
         unsigned char* ob = reinterpret_cast<unsigned char*>(a.out) + ((long)b * 2 * a.H + 4 * ty) * orow_bytes + tx * (32 * 128);
         const unsigned char* ps = patch + pbuf * UP_PATCH_BYTES;
 #pragma unroll
@@ -305,15 +295,12 @@ static bool try_launch_up_bf16(const GemmPlan& P, const void* in, const void* wp
     UpArgs a;
     a.in = in; a.wp = wp; a.out = out; a.scale = scale; a.shift = shift;
     a.B = P.B; a.H = P.Hin; a.W = P.Win; a.Ktot = P.Ktot; a.relu = relu;
-    a.ntx = P.Win / 16; a.tpi = a.ntx * (P.Hin / 2);
-    a.one_ntx = a.ntx == 1; a.one_tpi = a.tpi == 1;
-    a.inv_ntx = a.ntx > 1 ? (unsigned)(((1ull << 32) + a.ntx - 1) / a.ntx) : 0u;
-    a.inv_tpi = a.tpi > 1 ? (unsigned)(((1ull << 32) + a.tpi - 1) / a.tpi) : 0u;
+    make_tile_grid(P.Win / 16, P.Hin / 2, 0, a.g);
     for (int i = 0; i < 4; ++i) {
         a.koff[i] = P.ph[i].koff;
         for (int t = 0; t < 4; ++t) { a.dy[i][t] = P.ph[i].dy[t]; a.dx[i][t] = P.ph[i].dx[t]; }
     }
-    const int ntiles = P.B * a.tpi;
+    const int ntiles = P.B * a.g.tpi;
     a.tiles_per_wg = (ntiles + 255) / 256;                 // one workgroup per CU (a wave per SIMD with all its registers)
     const int gx = (ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     static LdsOptIn lds_opt;
