@@ -263,8 +263,9 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     // that just served them; otherwise tiles are strided over the grid.
     const bool imo = IN_SS || STATS || a.B >= (int)gridDim.x;    // (the feature launches have at most one workgroup per image)
     const int tgrp = imo ? tpi : 1;                                   // (one branch-free form for both orders)
+    const int imo_i = imo ? 1 : 0;
     auto tile_at = [&](int i) -> int {
-        const int j = imo ? a.g.div_tpi(i) : i;
+        const int j = i + (a.g.div_tpi(i) - i) * imo_i;               // imo ? i / tpi : i, without the branch a ?: becomes
         return ((int)blockIdx.x + j * (int)gridDim.x) * tgrp + (i - j * tgrp);
     };
     const int nit = imo ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * tpi

@@ -13,6 +13,7 @@
 #include "conv_rgb.hpp"
 #include "conv_down.hpp"
 #include "conv_up.hpp"
+#include "conv_mid.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -52,6 +53,7 @@ static std::atomic<int> g_opt_wreg{1};
 static std::atomic<int> g_opt_rgb{1};
 static std::atomic<int> g_opt_down{1};
 static std::atomic<int> g_opt_up{1};
+static std::atomic<int> g_opt_mid{1};
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
@@ -81,6 +83,7 @@ int dvae_set_option(const char* name, int value) {
     if (!strcmp(name, "conv_rgb")) { g_opt_rgb.store(value != 0); return DVAE_OK; }
     if (!strcmp(name, "conv_down")) { g_opt_down.store(value != 0); return DVAE_OK; }
     if (!strcmp(name, "conv_up")) { g_opt_up.store(value != 0); return DVAE_OK; }
+    if (!strcmp(name, "conv_mid")) { g_opt_mid.store(value != 0); return DVAE_OK; }
     DVAE_FAIL(DVAE_EINVAL, "set_option: unknown option '%s'", name);
 }
 const char* dvae_last_error(void) { return g_err; }
@@ -205,6 +208,10 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
         DVAE_CHECK_LAUNCH("conv_up");
         return DVAE_OK;
     }
+    if (g_opt_mid.load() && try_launch_mid_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_mid");
+        return DVAE_OK;
+    }
     if (try_launch_image_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st))) {
         DVAE_CHECK_LAUNCH("conv_image");
         return DVAE_OK;
@@ -248,6 +255,10 @@ int dvae_conv_dgrad(const void* dy, const void* wp, void* dx, int accumulate, co
     }
     if (try_launch_halo_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
         DVAE_CHECK_LAUNCH("conv_halo");
+        return DVAE_OK;
+    }
+    if (g_opt_mid.load() && try_launch_mid_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {
+        DVAE_CHECK_LAUNCH("conv_mid");
         return DVAE_OK;
     }
     if (try_launch_image_bf16(P, dy, wp, dx, nullptr, nullptr, nullptr, 0, accumulate, 0, S(st))) {

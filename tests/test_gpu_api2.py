@@ -489,9 +489,11 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
       f32-trained, bf16-trained
                    D-VAEs trained AND run in fp32 / in bf16 (what bench.py times).  Every training run is another network,
                    and a 960-step D-VAE is a noisy purifier: with nothing changed but the order of the batches the clean
-                   accuracy behind it moves between 59 and 71 % in either dtype (a summation-order change in one conv
-                   kernel re-rolls it just the same).  So the claim that matters -- training in bf16 purifies as well as
-                   training in fp32 -- is held on the mean over three trainings each: bf16 >= f32 - 6 points
+                   accuracy behind it moves between 59 and 71 % in either dtype, and now and then a run does not learn to
+                   separate the poison at all and lands at the poisoned control (52 % seen, in both dtypes on the same
+                   batch order); a summation-order change in one conv kernel re-rolls all of it just the same.  So the claim
+                   that matters -- training in bf16 purifies as well as training in fp32 -- is held on the median over
+                   three trainings each (one collapsed run does not move it): bf16 >= f32 - 6 points
       sign-error   the fp32 path with the perturbation added instead of subtracted: a purifier with one defect must land
                    outside the +-1 band (below oracle by more than 3 points), else the leg could not see it
     and the purified arms must recover >= 8 points over the poisoned control."""
@@ -534,7 +536,7 @@ def test_downstream_accuracy_of_purified_data_oracle_vs_hip():
             mt = m if (dt, seed) == ("f32", 2) else _train_dvae(ds, test, dt, seed=seed)
             sdt = {k: v.detach().cpu().clone() for k, v in mt.state_dict().items()}
             trained[dt].append(_classifier_accuracy(_purify_hip(sdt, ds, eps, dt), ds.targets, test))
-        accs[dt + "-trained"] = float(np.mean(trained[dt]))
+        accs[dt + "-trained"] = float(np.median(trained[dt]))
     print("clean test accuracy (%) behind three D-VAE trainings per dtype:", {k: [round(a, 2) for a in v] for k, v in trained.items()})
     # the classifier stage itself in bf16 on the oracle-purified set
     accs["oracle, bf16 classifier"] = _classifier_accuracy(purified["oracle"], ds.targets, test, act_dtype="bf16")

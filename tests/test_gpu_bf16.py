@@ -297,6 +297,8 @@ PERSISTENT = [
     (128, 64, 4, 2, 1, True, 16, "bnrelu", 37),   # transposed-conv weights-in-registers kernel: 2 tiles per workgroup, scale / shift / ReLU
     (128, 64, 4, 2, 1, True, 16, "plain", 161),   # ... 6 tiles per workgroup, 4 in the last
     (128, 64, 4, 2, 1, True, 48, "bnrelu", 60),   # ... 72 tiles per image: three across
+    (128, 128, 3, 1, 1, False, 16, "plain", 100), # 128 -> 128 weights-in-registers kernel without a residual: 1.6 tiles per workgroup
+    (128, 128, 3, 1, 1, False, 16, "bnrelu", 321),  # ... 5.02 tiles per workgroup: the last one short
 ]
 
 
@@ -361,6 +363,42 @@ def test_up_conv_epilogue(hin, B):
         L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), yb.data_ptr(), C.byref(d), L.BF16, st))
     finally:
         L.check(lib.dvae_set_option(b"conv_up", 1))
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("hin,B,res", [(16, 1, True), (16, 7, False), (16, 64, True), (32, 3, True), (48, 2, True), (112, 1, False)])
+def test_mid_conv_epilogue(hin, B, res):
+    """Conv2d 3x3 128 -> 128 (resnet.py:26-31: a BasicBlock's second conv in layer2) with the folded BatchNorm + shortcut +
+    ReLU epilogue of the inference path (resnet.py:43-47), against torch on the bf16-rounded operands: <= 6e-3 of scale
+    (one bf16 rounding); and against the image-resident kernel on the same launch (the dedicated kernel switched off):
+    the same fp32 sums in the same order, so the same bits."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(13)
+    q = lambda t: t.bfloat16().float()      # noqa: E731
+    w = q(torch.randn(128, 128, 3, 3, generator=g) / 34.0)
+    x = q(torch.randn(B, 128, hin, hin, generator=g))
+    r = q(torch.randn(B, 128, hin, hin, generator=g)) if res else None
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    want = F.conv2d(x, w, None, stride=1, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    want = torch.relu(want + r if res else want)
+    d = L.ConvDesc(B, hin, hin, 128, 128, 3, 3, 1, 1, 0)
+    st = L.stream()
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    ya = torch.full((B, hin, hin, 128), 7.0, device="cuda", dtype=torch.bfloat16)
+    scd, shd = sc.cuda(), sh.cuda()
+    ra = to_act(r, L.BF16) if res else None
+    ep = L.Epilogue(scd.data_ptr(), shd.data_ptr(), None if ra is None else ra.data_ptr(), 1, 0)
+    xa = to_act(x, L.BF16)
+    L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), ya.data_ptr(), C.byref(d), L.BF16, st))
+    assert rel_err(from_act(ya, 128), want) < 6e-3
+    yb = torch.full_like(ya, 7.0)
+    L.check(lib.dvae_set_option(b"conv_mid", 0))
+    try:
+        L.check(lib.dvae_conv_fwd(xa.data_ptr(), pk.data_ptr(), C.byref(ep), yb.data_ptr(), C.byref(d), L.BF16, st))
+    finally:
+        L.check(lib.dvae_set_option(b"conv_mid", 1))
     torch.cuda.synchronize()
     assert torch.equal(ya, yb)
 
