@@ -33,6 +33,27 @@ from dvae_amd.engine import DVAEConfig, DVAEEngine  # noqa: E402
 FWD_MACS = 418_775_040           # one model_s forward, classifier head excluded (per image, 32x32)
 TRAIN_MACS = 1_254_555_648       # forward + dgrad + wgrad, no dgrad for conv1
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, gfx950
+# Algorithmic HBM bytes of one bf16 inference forward as it is launched, per 32x32 image: every launch's input (+ residual)
+# read once and its output written once, weights and statistics not counted.  (name, bytes read, bytes written)
+FWD_BYTES_BF16 = [
+    ("uint8 -> 8-channel input", 3 * 1024, 16 * 1024),
+    ("conv1 3 -> 64", 16 * 1024, 128 * 1024),
+    ("layer1.0.conv1", 128 * 1024, 128 * 1024),
+    ("layer1.0.conv2 + residual", 256 * 1024, 128 * 1024),
+    ("layer1.1.conv1", 128 * 1024, 128 * 1024),
+    ("layer1.1.conv2 + residual", 256 * 1024, 128 * 1024),
+    ("layer2.0.conv1 (stride 2)", 128 * 1024, 64 * 1024),
+    ("layer2.0.shortcut (every other pixel of every other row)", 32 * 1024, 64 * 1024),
+    ("layer2.0.conv2 + residual", 128 * 1024, 64 * 1024),
+    ("fc_mu | fc_var + reparameterisation + post_conv, one launch: two outputs (z' and z' + class embedding)", 64 * 1024, 128 * 1024),
+] + 2 * [
+    ("decoder ConvT 4x4 128 -> 64", 64 * 1024, 128 * 1024),
+    ("decoder ConvT 3x3 64 -> 64", 128 * 1024, 128 * 1024),
+    ("decoder ConvT 3x3 64 -> 32", 128 * 1024, 64 * 1024),
+    ("decoder ConvT 3x3 32 -> 3 (fp32 out, 4 channels stored)", 64 * 1024, 16 * 1024),
+]
+FWD_HBM_BYTES_BF16 = sum(r + w for _, r, w in FWD_BYTES_BF16)     # 3.7 MB per image and forward
+HBM_PEAK_GBS = 8000.0
 CONV_PROBE = "layer1.0.conv1"    # 3x3 64->64 @ 32x32: the shape that carries most of the FLOPs
 CONV_PROBE_MACS = 64 * 64 * 9 * 32 * 32
 
@@ -403,6 +424,14 @@ def main():
                             "purify": {"achieved": res["purify_tflops"], "frac": res["purify_tflops"] / peak},
                             "train": ({"achieved": res["train_tflops"], "frac": res["train_tflops"] / peak}
                                       if train_ips else None)}
+    if a.dtype == "bf16":
+        # ... and against the HBM peak of its activations' traffic: every layer is a launch of its own, so every activation
+        # is written once and read once (twice where it is also a residual); 288 FLOP/B for the 64-channel convs against a
+        # ridge of 312: the step sits on both roofs at once
+        gbs = (1 + a.stage) * FWD_HBM_BYTES_BF16 * px * purify_ips / 1e9
+        res["step_roofline"]["purify_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                              "frac": gbs / (HBM_PEAK_GBS * world),
+                                              "algorithmic_bytes_per_image_forward": FWD_HBM_BYTES_BF16 * px}
     if f32_leg is not None:
         res["f32"] = f32_leg
         res["value_f32"] = f32_leg["value"]               # the reference's own precision, same run

@@ -70,6 +70,9 @@ _SIGS = {
     "dvae_norm_stats_from_chunks": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "dvae_fc_reparam_supported": (C.c_int, [C.POINTER(ConvDesc), _I, _I]),
     "dvae_fc_reparam_fwd_philox": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P, _L, C.c_uint64, C.c_uint32, _I, _P]),
+    "dvae_fc_reparam_post_supported": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _I, _I]),
+    "dvae_fc_reparam_post_fwd_philox": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.POINTER(ConvDesc), C.POINTER(ConvDesc),
+                                                   _I, _P, _L, C.c_uint64, C.c_uint32, _I, _P]),
     "dvae_reparam_kl_fwd_philox": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _L, C.c_uint64, C.c_uint32, _I, _P]),
     "dvae_reparam_kl_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dvae_recon_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),

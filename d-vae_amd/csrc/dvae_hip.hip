@@ -14,6 +14,7 @@
 #include "conv_down.hpp"
 #include "conv_up.hpp"
 #include "conv_mid.hpp"
+#include "head_post.hpp"
 #include "norm.hpp"
 
 namespace dvae {
@@ -691,6 +692,34 @@ int dvae_fc_reparam_fwd_philox(const void* x, const void* wp, const float* bias,
         return DVAE_OK;
     }
     return launch_igemm_zf(P, x, wp, bias, z, L, key, S(st));
+}
+
+int dvae_fc_reparam_post_supported(const dvae_conv_desc* d_fc, const dvae_conv_desc* d_post, int L, int dtype) {
+    GemmPlan P1, P2;
+    if (!d_fc || !d_post || dtype != DVAE_BF16 || build_plan(*d_fc, DVAE_OP_FWD, dtype, P1) ||
+        build_plan(*d_post, DVAE_OP_FWD, dtype, P2))
+        return 0;
+    return head_post_applicable(P1, P2, L) ? 1 : 0;
+}
+
+int dvae_fc_reparam_post_fwd_philox(const void* x, const void* wp_fc, const float* bias_fc, const void* wp_post,
+                                    const float* bias_post, void* out, const void* emb_table, const int64_t* emb_labels,
+                                    void* emb_out, int emb_plain, const dvae_conv_desc* d_fc, const dvae_conv_desc* d_post,
+                                    int L, const int32_t* index, int64_t first, uint64_t seed, uint32_t stream_id, int dtype,
+                                    void* st) {
+    GemmPlan P1, P2;
+    if (!d_fc || !d_post || !x || !wp_fc || !bias_fc || !wp_post || !out) DVAE_FAIL(DVAE_EINVAL, "fc_reparam_post: null argument");
+    if (emb_out && (!emb_table || !emb_labels)) DVAE_FAIL(DVAE_EINVAL, "fc_reparam_post: second output without table / labels");
+    if (dtype != DVAE_BF16) DVAE_FAIL(DVAE_EDTYPE, "fc_reparam_post: bf16 only (see dvae_fc_reparam_post_supported)");
+    int rc = build_plan(*d_fc, DVAE_OP_FWD, dtype, P1);
+    if (rc) return rc;
+    rc = build_plan(*d_post, DVAE_OP_FWD, dtype, P2);
+    if (rc) return rc;
+    if (!head_post_applicable(P1, P2, L)) DVAE_FAIL(DVAE_EINVAL, "fc_reparam_post: shape not supported (see dvae_fc_reparam_post_supported)");
+    PhiloxKey key = {index, (long)first, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id};
+    launch_head_post(P1, P2, x, wp_fc, bias_fc, wp_post, bias_post, out, emb_table, emb_labels, emb_out, emb_plain, key, S(st));
+    DVAE_CHECK_LAUNCH("head_post");
+    return DVAE_OK;
 }
 
 int dvae_reparam_kl_bwd(const void* dz1, const float* mulv, const float* eps, const float* scal, void* dmulv, int rows,

@@ -232,6 +232,9 @@ class DVAEEngine:
         self._fuse_stats = all(self.lib.dvae_conv_out_stats_floats(C.byref(self._desc(self.specs[n], 1)), dtype) > 0
                                for n in ("decoder1.1", "decoder2.0"))
         self._fuse_head = bool(self.lib.dvae_fc_reparam_supported(C.byref(self._desc(self.specs["fc"], 1)), self.Ld, dtype))
+        # ... and the whole latent path (fc, reparameterisation, post_conv) can be one launch that never writes z
+        self._fuse_head_post = bool(self._fuse_head and self.lib.dvae_fc_reparam_post_supported(
+            C.byref(self._desc(self.specs["fc"], 1)), C.byref(self._desc(self.specs["post_conv"], 1)), self.Ld, dtype))
         # post_conv can leave decoder_p's input (z + class embedding) behind as a second output
         # (either table: the spatial one, or the plain class embedding -- one row for every pixel of an image)
         self._fuse_emb = bool(cfg.sample_wise and not cfg.use_y and
@@ -610,6 +613,17 @@ class DVAEEngine:
         # (halves the largest tensor of the forward pass on the bf16 path).  Training keeps them fp32.
         lean = isinstance(eps, PhiloxEps) and not keep_eps and self.dtype == BF16
         z1 = self.act("z1", h, self.Ld)
+        if lean and self._fuse_head_post and not need_mulv:
+            # one launch for fc, reparameterisation and post_conv: mu, log_var and z1 never exist in memory (z1's buffer
+            # keeps whatever an earlier call left)
+            z = self.act("z", h, 128)
+            et, el, eo = emb if emb is not None else (None, None, None)
+            check(self.lib.dvae_fc_reparam_post_fwd_philox(
+                ptr(stem_out), ptr(self.packed[("fc", L.OP_FWD)]), ptr(self.param["fc.bias"]),
+                ptr(self.packed[("post_conv", L.OP_FWD)]), ptr(self.param["post_conv.bias"]), ptr(z), ptr(et), ptr(el), ptr(eo),
+                int(emb is not None and not self.cfg.spatial_emb), C.byref(self.desc("fc", b)), C.byref(self.desc("post_conv", b)),
+                self.Ld, ptr(eps.index), eps.first, self.seed, eps.stream_id, self.dtype, L.stream()))
+            return None, z1, z
         if lean and self._fuse_head and not need_mulv:
             # one launch: mu / log_var never leave the registers of the GEMM that makes them
             check(self.lib.dvae_fc_reparam_fwd_philox(ptr(stem_out), ptr(self.packed[("fc", L.OP_FWD)]), ptr(self.param["fc.bias"]),

@@ -222,6 +222,18 @@ int dvae_fc_reparam_fwd_philox(const void* x, const void* wp, const float* bias,
                                int L, const int32_t* image_index /* [B] or NULL */, int64_t first_image,
                                uint64_t seed, uint32_t stream_id, int dtype, void* stream);
 
+/* The whole inference latent path in one launch: fc_mu|fc_var, the reparameterisation (as dvae_fc_reparam_fwd_philox) and
+ * post_conv (resnet.py:2197-2199: packed forward weights of the 1x1 conv latent -> 128, bias fp32 [128] or NULL), with
+ * post_conv's optional second output emb_out = out + emb_table[emb_labels[image]][pixel] (resnet.py:2212, :2219; emb_plain:
+ * one table row per class) as in dvae_epilogue.  z itself is never written.  Same bits as the two launches it replaces.
+ * dvae_fc_reparam_post_supported: bf16, L = 256, 128 stem channels, H * W a multiple of 64. */
+int dvae_fc_reparam_post_supported(const dvae_conv_desc* d_fc, const dvae_conv_desc* d_post, int L, int dtype);
+int dvae_fc_reparam_post_fwd_philox(const void* x, const void* wp_fc, const float* bias_fc, const void* wp_post,
+                                    const float* bias_post, void* out, const void* emb_table, const int64_t* emb_labels,
+                                    void* emb_out, int emb_plain, const dvae_conv_desc* d_fc, const dvae_conv_desc* d_post,
+                                    int L, const int32_t* image_index /* [B] or NULL */, int64_t first_image, uint64_t seed,
+                                    uint32_t stream_id, int dtype, void* stream);
+
 /* ---- reconstruction losses (main_vae_disentangle.py:190-192, :205-207) -----------------------
  * rec_pre and p (the decoders' 3-channel outputs, written by dvae_conv_fwd with out_f32) are fp32
  * [npix][4]; x is an act tensor; rec = sigmoid(rec_pre) is written fp32 [npix][4]; d_rec_pre / d_p are

@@ -217,6 +217,34 @@ def test_purification_bf16_close_to_fp32_and_shard_invariant(stage):
     assert torch.equal(out3, outs["bf16"][0]) and torch.equal(noise3, outs["bf16"][1])
 
 
+@pytest.mark.parametrize("batch", [64, 1000])
+def test_one_launch_latent_path_equals_the_two_launches(batch):
+    """fc_mu | fc_var + reparameterisation + post_conv (resnet.py:2245-2246, :2257-2259, :2197-2199) as one launch that
+    never writes z, against the fused head followed by the post_conv launch: the same arithmetic in the same order, so
+    post_conv's two outputs (z' and z' + class embedding, resnet.py:2212) and the purified bytes are equal bit for bit."""
+    _, eng, _ = _engine(L.BF16, 1024)
+    assert eng._fuse_head_post, "the one-launch latent path does not serve the CIFAR shape"
+    N = 2000
+    rng = np.random.default_rng(11)
+    data = torch.from_numpy(rng.integers(0, 256, (N, 32, 32, 3), dtype=np.uint8)).cuda()
+    labels = (torch.arange(N, device="cuda") % 10).long()
+    eng.seed = 3
+    res = []
+    for fused in (True, False):
+        eng._fuse_head_post = fused
+        out = torch.zeros_like(data)
+        noise = torch.zeros(N, 3, 32, 32, device="cuda")
+        for lo in range(0, N, batch):
+            eng.purify_batch(data, out, noise, labels, lo, min(batch, N - lo), 1)
+        torch.cuda.synchronize()
+        b = min(batch, N - (N - 1) // batch * batch)          # the last launch's images are what the buffers still hold
+        res.append((out, noise, eng.act("z", eng.h, 128)[:b].clone(), eng.act("dec_p.in", eng.h, 128)[:b].clone()))
+    eng._fuse_head_post = True
+    assert int(res[0][0].max()) > 0 and torch.isfinite(res[0][1]).all()
+    for got, want, what in zip(res[0], res[1], ("purified images", "perturbation", "post_conv output", "decoder_p input")):
+        assert torch.equal(got, want), what
+
+
 def test_purification_at_the_benchmark_batch_equals_small_batches():
     """Stage-1 purification (main_vae_disentangle.py:59-69) at the benchmark's 1024 images per launch -- every
     persistent kernel in steady state -- leaves exactly the bytes that 128-image launches leave: uint8 images and the
