@@ -244,7 +244,7 @@ class DVAEEngine:
         # to bf16 there); fp32 engines from the 24-bit stream.  Settable: an fp32 engine with this set draws the same
         # numbers as a bf16 one.
         self.inference_noise16 = dtype == BF16
-        self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events
+        self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events; cleared by that launch
         self._overlap = self.dev.type == "cuda"   # weight gradients on a side stream (see _wgrad)
         self._two_stream_decoders = os.environ.get("DVAE_TWO_STREAM_DECODERS", "1") != "0"
 
@@ -372,6 +372,7 @@ class DVAEEngine:
                                      C.byref(self.desc(name, b)), self.dtype, L.stream()))
         if pr:
             pr[1][1].record()
+            self.probe = None                              # one launch per request (an event pair costs its stream ~12 us)
 
     def _dgrad(self, name, dy, dx, b, accumulate=False):
         check(self.lib.dvae_conv_dgrad(ptr(dy), ptr(self.packed[(name, L.OP_DGRAD)]), ptr(dx), int(accumulate),
