@@ -44,6 +44,32 @@ def test_conv_plan_rejects_bad_descriptors():
     assert lib.dvae_conv_wgrad_workspace_bytes(C.byref(ok)) > 0
 
 
+def test_one_launch_latent_path_says_what_it_serves():
+    """dvae_fc_reparam_post_supported (host logic only): the one-launch latent path (resnet.py:2245-2246, :2257-2259,
+    :2197-2199) serves bf16, 256 latents on 128 stem channels and maps of a multiple of 64 pixels; everything else is
+    refused by the entry point with an error, not computed some other way."""
+    import ctypes as C
+    lib = L.lib()
+
+    def descs(h, latent):
+        return (L.ConvDesc(4, h, h, 128, 2 * latent, 1, 1, 1, 0, 0), L.ConvDesc(4, h, h, latent, 128, 1, 1, 1, 0, 0))
+
+    fc, post = descs(16, 256)
+    assert lib.dvae_fc_reparam_post_supported(C.byref(fc), C.byref(post), 256, L.BF16) == 1
+    assert lib.dvae_fc_reparam_post_supported(C.byref(fc), C.byref(post), 256, L.F32) == 0
+    for h, latent in ((16, 128), (4, 256), (112, 256)):
+        fc2, post2 = descs(h, latent)
+        want = 1 if (latent == 256 and (h * h) % 64 == 0) else 0
+        assert lib.dvae_fc_reparam_post_supported(C.byref(fc2), C.byref(post2), latent, L.BF16) == want, (h, latent)
+    fc3, post3 = descs(4, 256)
+    rc = lib.dvae_fc_reparam_post_fwd_philox(1, 1, 1, 1, None, 1, None, None, None, 0, C.byref(fc3), C.byref(post3), 256, None, 0, 0, 0,
+                                             L.BF16, None)
+    assert rc == -1 and b"fc_reparam_post" in lib.dvae_last_error()
+    rc = lib.dvae_fc_reparam_post_fwd_philox(1, 1, 1, 1, None, 1, None, None, None, 0, C.byref(fc), C.byref(post), 256, None, 0, 0, 0,
+                                             L.F32, None)
+    assert rc == -2
+
+
 @pytest.mark.parametrize("tag,seb,spatial", [("seb7_spatial", 7, True), ("seb9_flat", 9, False)])
 def test_state_dict_layout_matches_reference(golden_dir, tag, seb, spatial):
     ref = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))[tag]
