@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void head_post_bf16_kernel(const HeadPostArgs 
             u32x4 xv[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) xv[s] = *reinterpret_cast<const u32x4*>(xrow + 32 * s);
-            asm volatile("s_nop 4" ::: "memory");          // the bias moves -> the MFMAs' C operand
+            asm volatile("s_nop 4" : "+v"(acc[0]), "+v"(acc[1]));   // the bias moves -> the MFMAs' C operand (tied to the registers: nothing moves across)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 mfma_acc_a(acc[0], w1r[0][s], xv[s]);
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void head_post_bf16_kernel(const HeadPostArgs 
             asm volatile("" : "+v"(e0));                   // (the first Philox round would otherwise be hoisted out of the loop)
             f32x4 e[4];
             philox_lane_quads(a.zkey, img, e0, h, e);
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results -> the VALU reads below
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));   // the last MFMAs' results -> the VALU reads below
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4 o;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512) void head_post_bf16_kernel(const HeadPostArgs 
                 if (s == 0) mfma_first_a(acc2, w2r[s], zv[s & 3]);
                 else mfma_acc_a(acc2, w2r[s], zv[s & 3]);
             }
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc2));
             unsigned char* prow = patch + cur * HP_PATCH_BYTES + (32 * pb2 + r) * HP_OPIX + pb2 * 128 + (32 * ob + 4 * h) * 2;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
