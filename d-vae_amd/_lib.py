@@ -28,7 +28,7 @@ class Epilogue(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("in_scale_shift", C.c_void_p), ("in_relu", C.c_int32),
                 ("out_stats", C.c_void_p), ("emb_table", C.c_void_p), ("emb_labels", C.c_void_p), ("emb_out", C.c_void_p),
-                ("emb_plain", C.c_int32)]
+                ("emb_plain", C.c_int32), ("reverse_walk", C.c_int32)]
 
 
 _P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t

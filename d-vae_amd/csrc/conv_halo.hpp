@@ -70,6 +70,7 @@ struct HaloArgs {
     float* stats;            // optional [B][tiles per image * 8][2][NS]: sum and sum of squares of the stored bf16 output
                              // over each wave's 32 pixels (for the normalisation that follows the conv), or null
     unsigned long long* stamps;   // profiling aid: [grid.x][64 tiles][8] cycle-counter samples of wave 0, or null
+    int rev;                 // conv_wreg, whole-image walks: a workgroup takes its images last to first
 };
 
 // One cycle-counter sample per phase boundary of a tile (wave 0, lane 0 of each workgroup; first 64 tiles).

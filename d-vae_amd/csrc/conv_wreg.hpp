@@ -264,9 +264,15 @@ __global__ __launch_bounds__(256) void conv_wreg_bf16_kernel(const HaloArgs a) {
     const bool imo = IN_SS || STATS || a.B >= (int)gridDim.x;    // (the feature launches have at most one workgroup per image)
     const int tgrp = imo ? tpi : 1;                                   // (one branch-free form for both orders)
     const int imo_i = imo ? 1 : 0;
+    // Reversed walk (a.rev, whole-image order only): the workgroup's images last to first, so that the launch as a whole
+    // sweeps the tensors from their end -- where the launch before it, sweeping forwards, has just finished writing, and
+    // the memory-side cache still holds what it wrote.
+    const int rev_i = (imo && a.rev) ? 1 : 0;
+    const int nimg_wg = (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto tile_at = [&](int i) -> int {
         const int j = i + (a.g.div_tpi(i) - i) * imo_i;               // imo ? i / tpi : i, without the branch a ?: becomes
-        return ((int)blockIdx.x + j * (int)gridDim.x) * tgrp + (i - j * tgrp);
+        const int jr = j + (nimg_wg - 1 - 2 * j) * rev_i;
+        return ((int)blockIdx.x + jr * (int)gridDim.x) * tgrp + (i - j * tgrp);
     };
     const int nit = imo ? ((a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * tpi
                         : (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -731,7 +737,7 @@ static bool wreg_applicable(const GemmPlan& P) {
 static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* wp, void* out, const float* scale,
                                  const float* shift, const void* res, int relu, int accumulate, int out_f32, hipStream_t st,
                                  unsigned long long* stamps = nullptr, const float* in_ss = nullptr, int in_relu = 0,
-                                 float* stats = nullptr) {
+                                 float* stats = nullptr, int reverse_walk = 0) {
     // (ReLU before the addition of the old output is the one order this kernel does not have; nothing asks for it)
     if (out_f32 || !wreg_applicable(P) || (res && accumulate) || (relu && accumulate)) return false;
     const bool feat = in_ss != nullptr || stats != nullptr;
@@ -750,6 +756,7 @@ static bool try_launch_wreg_bf16(const GemmPlan& P, const void* in, const void* 
     a.in_ss = in_ss; a.in_relu = in_relu; a.stats = stats;
     a.B = P.B; a.H = P.Hout; a.W = P.Wout; a.N = P.N; a.NS = P.NS; a.Ktot = P.Ktot;
     a.relu = relu; a.out_f32 = 0; a.stamps = stamps;
+    a.rev = reverse_walk;
     make_tile_grid(P.Wout / 32, P.Hout / 8, 0, a.g);
     memcpy(a.dy, ph.dy, 16); memcpy(a.dx, ph.dx, 16);
     const int ntiles = P.B * a.g.tpi;

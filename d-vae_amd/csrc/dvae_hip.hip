@@ -172,7 +172,7 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     if (!d) DVAE_FAIL(DVAE_EINVAL, "null desc");
     int rc = build_plan(*d, DVAE_OP_FWD, dtype, P);
     if (rc) return rc;
-    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    dvae_epilogue e = {nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (ep) e = *ep;
     if (e.out_stats && (dtype != DVAE_BF16 || e.out_f32 || !halo_features_applicable(P)))
         DVAE_FAIL(DVAE_EINVAL, "conv_fwd: fused output statistics are not available for this shape/dtype "
@@ -190,7 +190,7 @@ int dvae_conv_fwd(const void* x, const void* wp, const dvae_epilogue* ep, void* 
     }
     if (g_opt_wreg.load() &&
         try_launch_wreg_bf16(P, x, wp, y, e.scale, e.shift, e.residual, e.relu, 0, e.out_f32, S(st), nullptr, e.in_scale_shift,
-                             e.in_relu, e.out_stats)) {
+                             e.in_relu, e.out_stats, e.reverse_walk)) {
         DVAE_CHECK_LAUNCH("conv_wreg");
         return DVAE_OK;
     }

@@ -244,6 +244,12 @@ class DVAEEngine:
         # to bf16 there); fp32 engines from the 24-bit stream.  Settable: an fp32 engine with this set draws the same
         # numbers as a bf16 one.
         self.inference_noise16 = dtype == BF16
+        # Launches that sweep the batch last image to first (dvae_epilogue.reverse_walk: a scheduling hint, same results):
+        # the first conv of each layer1 block starts where its producer has just finished writing, and the block's second
+        # conv, sweeping forwards again, starts where the first one finished -- +1.2 % on the 2048-image purification step.
+        # DVAE_REVERSE_WALK=<comma-separated conv names> overrides the set ("-" for none).
+        rw = os.environ.get("DVAE_REVERSE_WALK")
+        self._reverse_walk = frozenset(("layer1.0.conv1", "layer1.1.conv1") if rw is None else [n for n in rw.split(",") if n and n != "-"])
         self.probe = None   # (conv name, (start_event, stop_event)): bench.py times one conv launch with HIP events; cleared by that launch
         self._overlap = self.dev.type == "cuda"   # weight gradients on a side stream (see _wgrad)
         self._two_stream_decoders = os.environ.get("DVAE_TWO_STREAM_DECODERS", "1") != "0"
@@ -364,7 +370,7 @@ class DVAEEngine:
         """emb = (packed table, labels, second output): the conv also writes y + table[label] (decoder_p's input)."""
         et, el, eo = emb if emb is not None else (None, None, None)
         ep = Epilogue(ptr(scale), ptr(shift), ptr(residual), int(relu), int(out_f32), ptr(in_ss), int(in_relu), ptr(out_stats),
-                      ptr(et), ptr(el), ptr(eo), int(emb is not None and not self.cfg.spatial_emb))
+                      ptr(et), ptr(el), ptr(eo), int(emb is not None and not self.cfg.spatial_emb), int(name in getattr(self, "_reverse_walk", ())))
         pr = self.probe if (self.probe is not None and self.probe[0] == name) else None
         if pr:
             pr[1][0].record()

@@ -81,6 +81,11 @@ typedef struct dvae_epilogue {
     void* emb_out;
     int32_t emb_plain;        /* 1: emb_table is the plain class embedding [classes][act channels] (spatial_emb off,
                                * resnet.py:2214-2216), one row for every pixel of an image; 0: the spatial table */
+    int32_t reverse_walk;     /* a scheduling hint, never a change of results: kernels that sweep the batch first image to
+                               * last take it last image to first.  A launch that starts where the launch before it has
+                               * just finished writing finds that data in the memory-side cache (tensors larger than the
+                               * cache: 2048-image batches); ignored by kernels that do not sweep.  No counterpart in the
+                               * reference. */
 } dvae_epilogue;
 
 const char* dvae_version(void);

@@ -714,6 +714,37 @@ def test_conv_output_statistics_bf16(cin, cout, hin, tr, B):
     assert rel_err(out["fused"][0][:, :cout].cpu(), y.mean(dim=(2, 3))) < 2e-5
 
 
+@pytest.mark.parametrize("cout,res,stats", [(64, False, False), (64, True, False), (64, False, True), (32, False, True)])
+def test_reverse_walk_changes_no_bit(cout, res, stats):
+    """dvae_epilogue.reverse_walk is a scheduling hint: the weights-in-registers 3x3 conv (resnet.py:26-31, :2139-2167)
+    sweeping a 700-image batch last image to first -- 2.7 images per workgroup, so the last workgroups have one image
+    fewer -- stores the same bytes, and the same output statistics, as sweeping it first to last."""
+    lib = L.lib()
+    B, hin, cin = 700, 32, 64
+    g = torch.Generator().manual_seed(23 + cout)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 24.0
+    x = torch.randn(B, hin, hin, cin, generator=g).cuda().bfloat16()
+    r = torch.randn(B, hin, hin, cout, generator=g).cuda().bfloat16() if res else None
+    sh = torch.randn(cout, generator=g).cuda()
+    d = L.ConvDesc(B, hin, hin, cin, cout, 3, 3, 1, 1, 0)
+    st = L.stream()
+    pk = torch.zeros(lib.dvae_conv_packed_elems(C.byref(d), L.OP_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.dvae_conv_pack(w.cuda().contiguous().data_ptr(), pk.data_ptr(), C.byref(d), L.OP_FWD, L.BF16, st))
+    n = lib.dvae_conv_out_stats_floats(C.byref(d), L.BF16) if stats else 0
+    got = []
+    for rev in (0, 1):
+        y = torch.full((B, hin, hin, cout), 5.0, device="cuda", dtype=torch.bfloat16)
+        ch = torch.full((max(n, 1),), float("nan"), device="cuda")
+        ep = L.Epilogue(None, sh.data_ptr(), L.ptr(r), int(res), 0, None, 0, ch.data_ptr() if stats else None, None, None, None, 0, rev)
+        L.check(lib.dvae_conv_fwd(x.data_ptr(), pk.data_ptr(), C.byref(ep), y.data_ptr(), C.byref(d), L.BF16, st))
+        torch.cuda.synchronize()
+        got.append((y, ch))
+    assert torch.isfinite(got[0][0].float()).all()
+    assert torch.equal(got[0][0], got[1][0])
+    if stats:
+        assert torch.isfinite(got[0][1]).all() and torch.equal(got[0][1], got[1][1])
+
+
 @pytest.mark.parametrize("cin,cout,B,f32out,hin", [(64, 32, 3, False, 32), (64, 32, 600, False, 32), (32, 3, 700, True, 32),
                                                    (64, 32, 300, False, 96), (32, 3, 300, True, 96)])
 def test_conv_input_normalisation_prologue_bf16(cin, cout, B, f32out, hin):
