@@ -14,7 +14,7 @@ import statistics as st
 import sys
 
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"       # usage: python scripts/summarize_profile.py [r02|r03] [images per probed launch]
-IMAGES = int(sys.argv[2]) if len(sys.argv) > 2 else 2048  # bench.py's default purification batch at 32x32 (1024 until the middle of round 3)
+IMAGES = int(sys.argv[2]) if len(sys.argv) > 2 else 2048  # bench.py's default purification batch at 32x32 (pass 1024 for traces taken with --purify-batch 1024)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
